@@ -1,0 +1,148 @@
+/* cphnsw_mi355x.h — C-ABI of the MI355X-native CP-HNSW layer-0 hot path.
+ *
+ * One shared library (libcphnsw_mi355x.so, built by hipcc for gfx950) replaces, for the
+ * query-time path only, what the reference binds through pybind11 in
+ * src/bindings.cpp:115-240 (class `cphnsw._core.CPIndex`):
+ *
+ *   reference interface (file:line)                      this header
+ *   ---------------------------------------------------  ------------------------------
+ *   CPIndex(dim, bits)          src/bindings.cpp:77-123   cph_create
+ *   ~CPIndex                                             cph_destroy
+ *   .load(path)                 src/bindings.cpp:227-232  cph_load   (v2 file, api/hnsw_index.hpp:305-443)
+ *   .save(path)                 src/bindings.cpp:220-225  cph_save   (api/hnsw_index.hpp:217-303)
+ *   .search(query,k)            src/bindings.cpp:146-175  cph_search
+ *   .search_batch(queries,k)    src/bindings.cpp:177-218  cph_search_batch / cph_search_batch_device
+ *   .size/.dim/.is_finalized    src/bindings.cpp:234-239  cph_size / cph_dim / cph_is_finalized
+ *   .build/.finalize            src/bindings.cpp:125-144  cph_build / cph_finalize
+ *
+ * Kernel-level hooks (parity tests and the roofline benchmark; they expose the units the
+ * reference implements in distance/fastscan_kernel.hpp, core/memory.hpp and
+ * encoder/rabitq_encoder.hpp):
+ *   cph_encode_query, cph_entry_point, cph_fastscan_block, cph_exact_l2, cph_fastscan_stream_*.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a cph_status; on
+ * failure cph_last_error() (thread-local) holds the message the reference would have
+ * thrown.  CPH_INVALID_ARGUMENT maps to Python ValueError (std::invalid_argument),
+ * CPH_RUNTIME_ERROR to RuntimeError (std::runtime_error), CPH_OUT_OF_MEMORY to MemoryError.
+ * The caller owns all buffers; the library owns the handle.  A handle is bound to one HIP
+ * device; concurrent searches on one handle are serialised internally.
+ * Returned ids are the reference's internal (post-BFS-reorder) node ids.
+ */
+#ifndef CPHNSW_MI355X_H
+#define CPHNSW_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cph_index cph_index;
+
+typedef enum {
+    CPH_OK = 0,
+    CPH_INVALID_ARGUMENT = 1,
+    CPH_RUNTIME_ERROR = 2,
+    CPH_OUT_OF_MEMORY = 3,
+    CPH_NOT_IMPLEMENTED = 4
+} cph_status;
+
+/* Thread-local message of the last failing call on this thread. */
+const char* cph_last_error(void);
+
+/* Library/ABI version (major*100 + minor). */
+int cph_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+/* dim > 0, next_pow2(dim) in {16..2048}, bits in {1,2,4}; device = HIP device ordinal. */
+int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out);
+int cph_destroy(cph_index* h);
+
+int cph_load(cph_index* h, const char* path);
+int cph_save(cph_index* h, const char* path);
+int cph_size(cph_index* h, uint64_t* n);
+int cph_dim(cph_index* h, uint64_t* dim);
+int cph_is_finalized(cph_index* h, int* flag);
+
+/* Host-side construction.  Until it lands these return
+ * CPH_NOT_IMPLEMENTED and indexes come from cph_load. */
+int cph_build(cph_index* h, const float* vectors, uint64_t n);
+int cph_finalize(cph_index* h);
+
+/* ---- search ---------------------------------------------------------------------- */
+/* queries: host, row-major [n][dim] float32.  ids/dist: host, [n][k], rows shorter than k
+ * padded with -1 / FLT_MAX (src/bindings.cpp:202-210). */
+int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k,
+                     int64_t* ids, float* dist);
+
+/* Same, but queries/ids/dist are DEVICE pointers on the handle's device and the work is
+ * enqueued on `stream` (a hipStream_t; NULL = default stream).  Nothing is copied to the
+ * host; returns after enqueueing unless a capacity overflow forces a re-run (then it
+ * synchronises the stream). */
+int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, uint64_t k,
+                            int64_t* d_ids, float* d_dist, void* stream);
+
+/* Single query; writes m <= max(k,1) results (unpadded, src/bindings.cpp:146-175). */
+int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
+               uint64_t* m);
+
+/* Tuning knobs (0 = automatic): resident query slots and per-slot beam capacity. */
+int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
+
+/* Per-batch work counters of the last search on this handle (sums over queries):
+ * out[0]=expansions (FastScan blocks), [1]=exact L2 evaluations, [2]=new neighbours,
+ * [3]=beam pushes, [4]=stage-2 skipped batches, [5]=queries re-run after overflow,
+ * [6]=kernel time of the last search in microseconds (HIP events), [7]=reserved. */
+int cph_last_search_stats(cph_index* h, uint64_t out[8]);
+
+/* ---- kernel-level hooks ------------------------------------------------------------ */
+/* Query encoder (encoder/rabitq_encoder.hpp:73-79,98-136,197-209): lut = u8[D/4][16] in
+ * the reference's LUT format, coeffs = {coeff_fastscan, coeff_popcount, coeff_constant}. */
+int cph_encode_query(cph_index* h, const float* query, uint8_t* lut, float* coeffs);
+
+/* Upper-layer greedy descent (api/hnsw_index.hpp:196-202,617-638): layer-0 entry id. */
+int cph_entry_point(cph_index* h, const float* query, uint32_t* entry);
+
+/* One 32-neighbour FastScan block on the GPU for vertex `vertex` of the loaded index:
+ * sums[32] (1-bit: plane sum; N-bit: weighted N-bit sum), msb[32] (plane-0 sum),
+ * est[32]/lower[32] as search consumes them (stage-2 skip applied when nn_full != 0 and
+ * no stage-1 lower bound is below `worst`: est = FLT_MAX, lower = stage-1 bound),
+ * lower_stage1[32] (convert_msb_to_lower_bounds; == lower for 1-bit).
+ * qparams = {coeff_fastscan, coeff_popcount, coeff_constant, affine_a, affine_b,
+ * ip_qo_floor, dot_slack}.  (distance/fastscan_kernel.hpp:17-425,
+ * search/rabitq_search.hpp:159-206) */
+int cph_fastscan_block(cph_index* h, const uint8_t* lut, const float* qparams,
+                       uint32_t vertex, float dist_qp_sq, float worst, int nn_full,
+                       uint32_t* sums, uint32_t* msb, float* est, float* lower,
+                       float* lower_stage1);
+
+/* Exact L2 (search/rabitq_search.hpp:90-93, core/memory.hpp:81-95) of `query` against
+ * nodes ids[0..n). */
+int cph_exact_l2(cph_index* h, const float* query, const uint32_t* ids, uint64_t n,
+                 float* out);
+
+/* Streaming FastScan roofline benchmark on synthetic neighbour blocks (no graph).
+ * create: allocates n_blocks device blocks of layout (D,bits) filled with seeded random
+ * valid codes/aux.  run: `reps` passes over all blocks with one encoded query, both
+ * N-bit stages per block; writes the average kernel time per pass (HIP events on the
+ * launch stream), and a checksum.  block_bytes = device bytes per block. */
+typedef struct cph_stream cph_stream;
+int cph_fastscan_stream_create(int device, uint32_t D, uint32_t bits, uint64_t n_blocks,
+                               uint64_t seed, cph_stream** out, uint64_t* block_bytes);
+int cph_fastscan_stream_run(cph_stream* s, int reps, double* avg_ms, double* checksum);
+/* Copies block `i` out in the REFERENCE neighbour-block layout
+ * (distance/fastscan_layout.hpp:51-92,114-155) and the query (lut u8[D/4][16], 7 qparams,
+ * dist_qp_sq) so a CPU implementation can be run on identical inputs. */
+int cph_fastscan_stream_export(cph_stream* s, uint64_t first, uint64_t count,
+                               uint8_t* ref_blocks, uint8_t* lut, float* qparams,
+                               float* dist_qp_sq);
+/* est/lower of block i as computed by the stream kernel (for parity checks). */
+int cph_fastscan_stream_eval(cph_stream* s, uint64_t first, uint64_t count, float* est,
+                             float* lower);
+int cph_fastscan_stream_destroy(cph_stream* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPHNSW_MI355X_H */

@@ -1,0 +1,7 @@
+"""cphnsw_mi355x — MI355X-native query path of CP-HNSW behind the reference's Python API.
+
+    from cphnsw_mi355x import CPIndex      # drop-in for `from cphnsw import CPIndex`
+"""
+from .index import CPIndex, FastScanStream  # noqa: F401
+
+__all__ = ["CPIndex", "FastScanStream"]

@@ -1,0 +1,221 @@
+"""`CPIndex` — drop-in for the reference's `cphnsw.CPIndex` (src/bindings.cpp:115-240) whose
+query path runs on an MI355X through the C-ABI in include/cphnsw_mi355x.h.
+
+Same constructor, methods, argument meaning, return shapes/dtypes and exception types as the
+pybind11 class.  Returned ids are the reference's internal (post-reorder) node ids.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_K = 10  # constants::kDefaultK
+
+
+def _as_f32(a):
+    # py::array_t<float, c_style | forcecast>
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+class CPIndex:
+    def __init__(self, dim, bits=1, device=None):
+        if dim < 0 or bits < 0:
+            raise TypeError("CPIndex(): incompatible constructor arguments")  # size_t in pybind11
+        if device is None:
+            device = _default_device()
+        self._h = C.c_void_p()
+        self._dim = int(dim)
+        self._bits = int(bits)
+        self._device = int(device)
+        _lib.check(_lib.lib().cph_create(int(dim), int(bits), int(device), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().cph_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # -- construction (host side) -------------------------------------------
+    def build(self, vectors):
+        v = _as_f32(vectors)
+        if v.ndim != 2 or v.shape[1] != self._dim:
+            raise ValueError("vectors must be a (n, dim) float32 array")
+        _lib.check(_lib.lib().cph_build(self._h, v.ctypes.data, v.shape[0]))
+
+    def finalize(self):
+        _lib.check(_lib.lib().cph_finalize(self._h))
+
+    # -- search -----------------------------------------------------------------------------
+    def search(self, query, k=DEFAULT_K):
+        q = _as_f32(query)
+        if q.ndim != 1 or q.shape[0] != self._dim:
+            raise ValueError("query must be 1D and match index dimension")
+        kk = max(int(k), 1)
+        ids = np.empty(kk, np.int64)
+        dist = np.empty(kk, np.float32)
+        m = C.c_uint64(0)
+        _lib.check(_lib.lib().cph_search(self._h, q.ctypes.data, int(k), ids.ctypes.data,
+                                         dist.ctypes.data, C.byref(m)))
+        return ids[:m.value].copy(), dist[:m.value].copy()
+
+    def search_batch(self, queries, k=DEFAULT_K):
+        q = _as_f32(queries)
+        if q.ndim != 2 or q.shape[1] != self._dim:
+            raise ValueError("queries must be a (n, dim) array")
+        n, k = q.shape[0], int(k)
+        ids = np.empty((n, k), np.int64)
+        dist = np.empty((n, k), np.float32)
+        _lib.check(_lib.lib().cph_search_batch(self._h, q.ctypes.data, n, k, ids.ctypes.data,
+                                               dist.ctypes.data))
+        return ids, dist
+
+    def search_batch_device(self, queries, k=DEFAULT_K, out=None, stream=None):
+        """Device-resident variant: `queries` is a float32 CUDA/HIP torch tensor (n, dim) on this
+        index' device; returns (ids int64, dist float32) torch tensors on the same device."""
+        import torch
+        if queries.dim() != 2 or queries.shape[1] != self._dim or queries.dtype != torch.float32:
+            raise ValueError("queries must be a (n, dim) array")
+        queries = queries.contiguous()
+        n, k = queries.shape[0], int(k)
+        if out is None:
+            ids = torch.empty((n, k), dtype=torch.int64, device=queries.device)
+            dist = torch.empty((n, k), dtype=torch.float32, device=queries.device)
+        else:
+            ids, dist = out
+        st = torch.cuda.current_stream(queries.device).cuda_stream if stream is None else stream
+        _lib.check(_lib.lib().cph_search_batch_device(self._h, queries.data_ptr(), n, k, ids.data_ptr(),
+                                                      dist.data_ptr(), C.c_void_p(st)))
+        return ids, dist
+
+    # -- persistence ------------------------------------------------------------------------
+    def save(self, path):
+        _lib.check(_lib.lib().cph_save(self._h, str(path).encode()))
+
+    def load(self, path):
+        _lib.check(_lib.lib().cph_load(self._h, str(path).encode()))
+
+    # -- properties -------------------------------------------------------------------------
+    @property
+    def size(self):
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().cph_size(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def is_finalized(self):
+        f = C.c_int(0)
+        _lib.check(_lib.lib().cph_is_finalized(self._h, C.byref(f)))
+        return bool(f.value)
+
+    # -- extras (not in the reference) ------------------------------------------------------
+    def set_search_params(self, slots=0, beam_capacity=0):
+        _lib.check(_lib.lib().cph_set_search_params(self._h, int(slots), int(beam_capacity)))
+
+    def last_search_stats(self):
+        out = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib().cph_last_search_stats(self._h, out))
+        keys = ("expansions", "exact_l2", "new_neighbours", "beam_pushes", "stage2_skipped",
+                "rerun_queries", "kernel_us", "slots_cap")
+        return dict(zip(keys, [int(x) for x in out]))
+
+    # kernel-level hooks (parity tests)
+    def encode_query(self, query):
+        q = _as_f32(query)
+        D = 1
+        while D < self._dim:
+            D *= 2
+        lut = np.zeros((D // 4, 16), np.uint8)
+        co = np.zeros(3, np.float32)
+        _lib.check(_lib.lib().cph_encode_query(self._h, q.ctypes.data, lut.ctypes.data, co.ctypes.data))
+        return lut, co
+
+    def entry_point(self, query):
+        q = _as_f32(query)
+        ep = C.c_uint32(0)
+        _lib.check(_lib.lib().cph_entry_point(self._h, q.ctypes.data, C.byref(ep)))
+        return ep.value
+
+    def fastscan_block(self, lut, qparams, vertex, dist_qp_sq, worst=3.402823466e+38, nn_full=False):
+        lut = np.ascontiguousarray(lut, np.uint8)
+        qp = np.ascontiguousarray(qparams, np.float32)
+        sums = np.zeros(32, np.uint32)
+        msb = np.zeros(32, np.uint32)
+        est = np.zeros(32, np.float32)
+        lower = np.zeros(32, np.float32)
+        lower1 = np.zeros(32, np.float32)
+        _lib.check(_lib.lib().cph_fastscan_block(
+            self._h, lut.ctypes.data, qp.ctypes.data, int(vertex), float(dist_qp_sq), float(worst),
+            int(bool(nn_full)), sums.ctypes.data, msb.ctypes.data, est.ctypes.data, lower.ctypes.data,
+            lower1.ctypes.data))
+        return sums, msb, est, lower, lower1
+
+    def exact_l2(self, query, ids):
+        q = _as_f32(query)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros(len(ids), np.float32)
+        _lib.check(_lib.lib().cph_exact_l2(self._h, q.ctypes.data, ids.ctypes.data, len(ids),
+                                           out.ctypes.data))
+        return out
+
+
+def _default_device():
+    """One process per GPU: LOCAL_RANK selects the device when launched by torch.distributed.run."""
+    import os
+    try:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    except ValueError:
+        return 0
+
+
+class FastScanStream:
+    """Synthetic-block streaming FastScan benchmark (cph_fastscan_stream_*)."""
+
+    def __init__(self, D, bits, n_blocks, seed=4, device=None):
+        self._h = C.c_void_p()
+        bb = C.c_uint64(0)
+        self.D, self.bits, self.n_blocks = int(D), int(bits), int(n_blocks)
+        dev = _default_device() if device is None else int(device)
+        _lib.check(_lib.lib().cph_fastscan_stream_create(dev, self.D, self.bits, self.n_blocks, int(seed),
+                                                         C.byref(self._h), C.byref(bb)))
+        self.block_bytes = bb.value
+
+    def run(self, reps=1):
+        ms = C.c_double(0)
+        ck = C.c_double(0)
+        _lib.check(_lib.lib().cph_fastscan_stream_run(self._h, int(reps), C.byref(ms), C.byref(ck)))
+        return ms.value, ck.value
+
+    def export(self, first, count, ref_block_bytes):
+        blocks = np.zeros(count * ref_block_bytes, np.uint8)
+        lut = np.zeros((self.D // 4, 16), np.uint8)
+        qp = np.zeros(7, np.float32)
+        dqp = C.c_float(0)
+        _lib.check(_lib.lib().cph_fastscan_stream_export(self._h, int(first), int(count), blocks.ctypes.data,
+                                                         lut.ctypes.data, qp.ctypes.data, C.byref(dqp)))
+        return blocks, lut, qp, dqp.value
+
+    def eval(self, first, count):
+        est = np.zeros((count, 32), np.float32)
+        lower = np.zeros((count, 32), np.float32)
+        _lib.check(_lib.lib().cph_fastscan_stream_eval(self._h, int(first), int(count), est.ctypes.data,
+                                                       lower.ctypes.data))
+        return est, lower
+
+    def close(self):
+        if self._h.value:
+            _lib.lib().cph_fastscan_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,831 @@
+// cphnsw_mi355x.hip — C-ABI of the MI355X-native CP-HNSW hot path (include/cphnsw_mi355x.h).
+//
+// Host orchestration only; the arithmetic lives in device_fastscan.h / device_search.h /
+// device_stream.h (GPU) and host_index.h (per-query feeders still on the host).
+// The product path has no CPU fallback: without a HIP device every compute entry point
+// fails with CPH_RUNTIME_ERROR.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cfloat>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/cphnsw_mi355x.h"
+#include "cph_core.h"
+#include "device_fastscan.h"
+#include "device_search.h"
+#include "device_stream.h"
+#include "host_index.h"
+
+using namespace cph;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct InvalidArg : std::invalid_argument {
+    using std::invalid_argument::invalid_argument;
+};
+
+#define HIP_CHECK(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            if (e_ == hipErrorOutOfMemory) throw std::bad_alloc();                        \
+            throw HipError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + \
+                           #expr);                                                        \
+        }                                                                                 \
+    } while (0)
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return CPH_OK;
+    } catch (const std::invalid_argument& e) {
+        return fail(CPH_INVALID_ARGUMENT, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(CPH_OUT_OF_MEMORY, "out of memory");
+    } catch (const std::exception& e) {
+        return fail(CPH_RUNTIME_ERROR, e.what());
+    }
+}
+
+size_t next_pow2(size_t n) {
+    size_t p = 1;
+    while (p < n) p *= 2;
+    return p;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        if (count <= n && p) return;
+        release();
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n / std::max<size_t>(min_chunk, 1)));
+    if (nt <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    size_t per = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; ++t) {
+        size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    for (auto& x : th) x.join();
+}
+
+// kernel dispatch over (bits, static D)
+template <template <int, int> class K, class Args>
+void dispatch(uint32_t bits, uint32_t D, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+              const Args& a);
+
+#define CPH_LAUNCH(KERNEL, bits, D, grid, block, lds, st, args)                                   \
+    do {                                                                                          \
+        const bool s128 = (D) == 128;                                                             \
+        if ((bits) == 1) {                                                                        \
+            if (s128) hipLaunchKernelGGL((KERNEL<1, 128>), grid, block, lds, st, args);           \
+            else hipLaunchKernelGGL((KERNEL<1, 0>), grid, block, lds, st, args);                  \
+        } else if ((bits) == 2) {                                                                 \
+            if (s128) hipLaunchKernelGGL((KERNEL<2, 128>), grid, block, lds, st, args);           \
+            else hipLaunchKernelGGL((KERNEL<2, 0>), grid, block, lds, st, args);                  \
+        } else {                                                                                  \
+            if (s128) hipLaunchKernelGGL((KERNEL<4, 128>), grid, block, lds, st, args);           \
+            else hipLaunchKernelGGL((KERNEL<4, 0>), grid, block, lds, st, args);                  \
+        }                                                                                         \
+        HIP_CHECK(hipGetLastError());                                                             \
+    } while (0)
+
+}  // namespace
+
+struct cph_index {
+    uint64_t dim = 0;
+    uint32_t bits = 0;
+    uint32_t D = 0;
+    int device = 0;
+    bool finalized = false;
+    HostIndex host;
+    DevLayout L{};
+    SearchConsts sc{};
+    uint32_t flags = 0;
+    int num_cus = 256;
+    // device-resident index
+    DevBuf<uint8_t> d_blocks;
+    DevBuf<float> d_raw, d_norm;
+    // per-batch query staging + outputs
+    DevBuf<float> d_queries;
+    DevBuf<uint4> d_qmasks;
+    DevBuf<QueryHeader> d_qhdr;
+    DevBuf<int64_t> d_ids;
+    DevBuf<float> d_dist;
+    DevBuf<uint32_t> d_count, d_status, d_todo;
+    DevBuf<uint32_t> d_counter;
+    DevBuf<unsigned long long> d_stats;
+    // per-slot scratch
+    DevBuf<uint32_t> d_bitmaps, d_logids;
+    DevBuf<uint2> d_heaps;
+    DevBuf<float> d_lowers;
+    uint32_t scratch_slots = 0;
+    uint64_t scratch_cap = 0;
+    // knobs
+    uint32_t want_slots = 0;
+    uint64_t want_cap = 0;
+    uint64_t last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+
+    void use_device() const { HIP_CHECK(hipSetDevice(device)); }
+};
+
+namespace {
+
+void require_finalized(cph_index* h) {
+    // the reference does not check (it would hit the invalid-entry RuntimeError or garbage,
+    // api/hnsw_index.hpp:203-205); we raise that error up front
+    if (!h->finalized) throw std::runtime_error("Search failed: invalid entry point after finalize.");
+}
+
+void upload_index(cph_index* h) {
+    h->use_device();
+    const HostIndex& hi = h->host;
+    h->L = make_dev_layout((uint32_t)hi.D, (uint32_t)hi.bw);
+    h->sc = hi.consts();
+    h->flags = hi.has_dup_neighbors ? 1u : 0u;
+    const size_t n = hi.n;
+    const size_t stride = h->L.stride;
+    h->d_blocks.alloc(n * stride + 64);
+    h->d_raw.alloc(n * hi.D);
+    h->d_norm.alloc(n);
+    // repack in chunks through a pinned staging buffer
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (256u << 20) / stride));
+    std::vector<uint8_t> stage(chunk * stride);
+    for (size_t base = 0; base < n; base += chunk) {
+        const size_t cnt = std::min(chunk, n - base);
+        parallel_for(cnt, 256, [&](size_t lo, size_t hi_) {
+            for (size_t v = lo; v < hi_; ++v)
+                repack_ref_to_dev(hi.nb(base + v), hi.RL, h->L, &stage[v * stride]);
+        });
+        HIP_CHECK(hipMemcpy(h->d_blocks.p + base * stride, stage.data(), cnt * stride,
+                            hipMemcpyHostToDevice));
+    }
+    HIP_CHECK(hipMemcpy(h->d_raw.p, hi.raw.data(), n * hi.D * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(h->d_norm.p, hi.norm_sq.data(), n * 4, hipMemcpyHostToDevice));
+    h->scratch_slots = 0;
+    h->scratch_cap = 0;
+}
+
+void ensure_scratch(cph_index* h, uint32_t slots, uint64_t cap) {
+    if (h->scratch_slots >= slots && h->scratch_cap == cap) return;
+    const uint64_t bm_words = (h->host.n + 31) / 32;
+    h->d_bitmaps.alloc((size_t)slots * bm_words);
+    HIP_CHECK(hipMemset(h->d_bitmaps.p, 0, (size_t)slots * bm_words * 4));
+    h->d_logids.alloc((size_t)slots * cap);
+    h->d_heaps.alloc((size_t)slots * cap);
+    h->d_lowers.alloc((size_t)slots * cap);
+    h->scratch_slots = slots;
+    h->scratch_cap = cap;
+}
+
+// Encode queries on the host (rotation, LUT scalars, upper-layer descent) and stage them.
+void stage_queries(cph_index* h, const float* queries, uint64_t nq, hipStream_t st) {
+    const HostIndex& hi = h->host;
+    const size_t D = hi.D, PW = h->L.PW, dim = hi.dim;
+    std::vector<float> padded(nq * D, 0.0f);
+    std::vector<uint32_t> masks(nq * PW * 4);
+    std::vector<QueryHeader> hdr(nq);
+    std::atomic<bool> bad{false};
+    parallel_for(nq, 16, [&](size_t lo, size_t hi_) {
+        std::vector<float> buf(D);
+        EncodedQuery eq;
+        for (size_t i = lo; i < hi_; ++i) {
+            float* p = &padded[i * D];
+            std::memcpy(p, queries + i * dim, dim * sizeof(float));
+            std::memcpy(buf.data(), p, D * sizeof(float));
+            encode_query(hi.rot, buf.data(), eq);
+            qu_to_masks(eq.qu.data(), D, &masks[i * PW * 4]);
+            hdr[i].A = eq.A; hdr[i].B = eq.B; hdr[i].C = eq.C;
+            uint32_t ep = hi.entry_point(p);
+            if (ep == kInvalidNode || ep >= hi.n) bad = true;
+            hdr[i].entry = ep;
+        }
+    });
+    if (bad) throw std::runtime_error("Search failed: invalid entry point after finalize.");
+    h->d_queries.alloc(nq * D);
+    h->d_qmasks.alloc(nq * PW);
+    h->d_qhdr.alloc(nq);
+    HIP_CHECK(hipMemcpyAsync(h->d_queries.p, padded.data(), nq * D * 4, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(h->d_qmasks.p, masks.data(), nq * PW * 16, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(h->d_qhdr.p, hdr.data(), nq * sizeof(QueryHeader), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // host vectors go out of scope
+}
+
+void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
+                   const uint32_t* d_todo, uint32_t slots, uint64_t cap, hipStream_t st) {
+    SearchArgs a{};
+    a.blocks = h->d_blocks.p;
+    a.raw = h->d_raw.p;
+    a.norm_sq = h->d_norm.p;
+    a.n = h->host.n;
+    a.L = h->L;
+    a.flags = h->flags;
+    a.queries = h->d_queries.p;
+    a.qmasks = h->d_qmasks.p;
+    a.qhdr = h->d_qhdr.p;
+    a.todo = d_todo;
+    a.nq = nq;
+    a.k = k;
+    a.sc = h->sc;
+    a.counter = h->d_counter.p;
+    a.cap = cap;
+    a.bm_words = (h->host.n + 31) / 32;
+    a.bitmaps = h->d_bitmaps.p;
+    a.heaps = h->d_heaps.p;
+    a.log_ids = h->d_logids.p;
+    a.lowers = h->d_lowers.p;
+    a.out_ids = d_ids;
+    a.out_dist = d_dist;
+    a.out_count = h->d_count.p;
+    a.status = h->d_status.p;
+    a.stats = h->d_stats.p;
+    HIP_CHECK(hipMemsetAsync(h->d_counter.p, 0, 4, st));
+    const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
+    if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+    CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
+}
+
+// Core: queries already staged in d_queries/d_qmasks/d_qhdr; results into device buffers.
+void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
+                hipStream_t st) {
+    const uint64_t n = h->host.n;
+    h->d_count.alloc(nq);
+    h->d_status.alloc(nq);
+    h->d_counter.alloc(1);
+    h->d_stats.alloc(8);
+    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 64, st));
+    // resident query slots: one wave each
+    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * 16;
+    uint32_t slots = std::min<uint32_t>(nq, max_slots);
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t bm_bytes = ((n + 31) / 32) * 4;
+    uint64_t cap = h->want_cap ? h->want_cap : std::min<uint64_t>(n + 1, 1u << 18);
+    cap = std::max<uint64_t>(64, std::min<uint64_t>(cap, n + 1));
+    if (!(h->scratch_slots >= slots && h->scratch_cap == cap)) {
+        // budget: at most 60% of what is free (plus what we already hold)
+        const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+        while (slots > 64 && (uint64_t)slots * (cap * 16 + bm_bytes) > budget) slots /= 2;
+        while (cap > 4096 && (uint64_t)slots * (cap * 16 + bm_bytes) > budget) cap /= 2;
+        ensure_scratch(h, slots, cap);
+    } else {
+        slots = std::min(slots, h->scratch_slots);
+    }
+    if (!h->ev0) { HIP_CHECK(hipEventCreate(&h->ev0)); HIP_CHECK(hipEventCreate(&h->ev1)); }
+    HIP_CHECK(hipEventRecord(h->ev0, st));
+    launch_search(h, nq, k, d_ids, d_dist, nullptr, slots, cap, st);
+    HIP_CHECK(hipEventRecord(h->ev1, st));
+    // overflow check needs the statuses
+    std::vector<uint32_t> status(nq);
+    HIP_CHECK(hipMemcpyAsync(status.data(), h->d_status.p, nq * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    std::vector<uint32_t> todo;
+    for (uint32_t i = 0; i < nq; ++i)
+        if (status[i] != kStatusOk) todo.push_back(i);
+    if (!todo.empty()) {
+        // exact re-run of the overflowed queries with full-capacity scratch
+        const uint64_t full = n + 1;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
+        uint64_t per = full * 16 + bm_bytes;
+        uint32_t s2 = (uint32_t)std::max<uint64_t>(
+            1, std::min<uint64_t>(todo.size(), (uint64_t)((free_b + held) * 0.6) / per));
+        h->d_bitmaps.release(); h->d_logids.release(); h->d_heaps.release(); h->d_lowers.release();
+        h->scratch_slots = 0; h->scratch_cap = 0;
+        ensure_scratch(h, s2, full);
+        h->d_todo.alloc(todo.size());
+        HIP_CHECK(hipMemcpyAsync(h->d_todo.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipEventRecord(h->ev0, st));
+        launch_search(h, (uint32_t)todo.size(), k, d_ids, d_dist, h->d_todo.p, s2, full, st);
+        HIP_CHECK(hipEventRecord(h->ev1, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms2 = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
+        ms += ms2;
+    }
+    unsigned long long stats[8];
+    HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) h->last_stats[i] = stats[i];
+    h->last_stats[5] = todo.size();
+    h->last_stats[6] = (uint64_t)(ms * 1000.0);
+    h->last_stats[7] = ((uint64_t)slots << 32) | (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char* cph_last_error(void) { return g_err.c_str(); }
+int cph_version(void) { return 100; }
+
+int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
+    return guarded([&] {
+        if (!out) throw InvalidArg("out must not be null");
+        *out = nullptr;
+        // src/bindings.cpp:100-113, :77-98; api/hnsw_index.hpp:90
+        if (bits != 1 && bits != 2 && bits != 4)
+            throw InvalidArg("Unsupported bits=" + std::to_string(bits) + ". Supported: 1, 2, 4.");
+        const size_t pd = next_pow2(dim);
+        if (dim == 0) throw InvalidArg("dim must be > 0");
+        if (pd < 16 || pd > 2048) {
+            if (pd < 16) {
+                // the reference pads only up to the next power of two; dims below 9 land on
+                // padded sizes it does not instantiate
+                throw InvalidArg("Unsupported dimension " + std::to_string(dim) + " (padded to " +
+                                 std::to_string(pd) +
+                                 "). Supported padded dims: 16, 32, 64, 128, 256, 512, 1024, 2048.");
+            }
+            throw InvalidArg("Unsupported dimension " + std::to_string(dim) + " (padded to " +
+                             std::to_string(pd) +
+                             "). Supported padded dims: 16, 32, 64, 128, 256, 512, 1024, 2048.");
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw std::runtime_error("No HIP device available: the MI355X path has no CPU fallback.");
+        if (device < 0 || device >= ndev) throw InvalidArg("invalid device ordinal");
+        auto* h = new cph_index();
+        h->dim = dim;
+        h->bits = (uint32_t)bits;
+        h->D = (uint32_t)pd;
+        h->device = device;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+        *out = h;
+    });
+}
+
+int cph_destroy(cph_index* h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipSetDevice(h->device);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        delete h;
+    });
+}
+
+int cph_load(cph_index* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->host.load(path, h->D, h->bits, h->dim);  // commits only on success
+        upload_index(h);
+        h->finalized = true;
+    });
+}
+
+int cph_save(cph_index* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->finalized) throw std::runtime_error("Index must be finalized before saving.");
+        h->host.save(path);
+    });
+}
+
+int cph_size(cph_index* h, uint64_t* n) {
+    return guarded([&] { *n = h->host.n; });
+}
+int cph_dim(cph_index* h, uint64_t* dim) {
+    return guarded([&] { *dim = h->dim; });
+}
+int cph_is_finalized(cph_index* h, int* flag) {
+    return guarded([&] { *flag = h->finalized ? 1 : 0; });
+}
+
+int cph_build(cph_index*, const float*, uint64_t) {
+    return fail(CPH_NOT_IMPLEMENTED,
+                "build() is host-side index construction (SURVEY.md §8f N2) and is not part of "
+                "this round's hot path; load() an index written by the reference instead.");
+}
+int cph_finalize(cph_index*) {
+    return fail(CPH_NOT_IMPLEMENTED,
+                "finalize() is host-side index construction (SURVEY.md §8f N2) and is not part "
+                "of this round's hot path; load() an index written by the reference instead.");
+}
+
+int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->want_slots = slots;
+        h->want_cap = beam_capacity;
+    });
+}
+
+int cph_last_search_stats(cph_index* h, uint64_t out[8]) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        for (int i = 0; i < 8; ++i) out[i] = h->last_stats[i];
+    });
+}
+
+int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k, int64_t* ids,
+                     float* dist) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        if (n == 0 || k == 0) {
+            // (n, 0) outputs: nothing to write; still validates the entry point like search()
+            return;
+        }
+        if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
+        h->use_device();
+        hipStream_t st = nullptr;
+        stage_queries(h, queries, n, st);
+        h->d_ids.alloc(n * k);
+        h->d_dist.alloc(n * k);
+        run_search(h, (uint32_t)n, (uint32_t)k, h->d_ids.p, h->d_dist.p, st);
+        HIP_CHECK(hipMemcpy(ids, h->d_ids.p, n * k * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dist, h->d_dist.p, n * k * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, uint64_t k,
+                            int64_t* d_ids, float* d_dist, void* stream) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        if (n == 0 || k == 0) return;
+        if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
+        h->use_device();
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        // the query encoder and the upper-layer descent still run on the host this round
+        // (SURVEY.md §8f N3 moves them on-device): round-trip the raw queries
+        std::vector<float> hq(n * h->dim);
+        HIP_CHECK(hipMemcpyAsync(hq.data(), d_queries, n * h->dim * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        stage_queries(h, hq.data(), n, st);
+        run_search(h, (uint32_t)n, (uint32_t)k, d_ids, d_dist, st);
+    });
+}
+
+int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
+               uint64_t* m) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        const uint64_t kk = std::max<uint64_t>(k, 1);  // api/hnsw_index.hpp:187
+        if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
+        h->use_device();
+        hipStream_t st = nullptr;
+        stage_queries(h, query, 1, st);
+        h->d_ids.alloc(kk);
+        h->d_dist.alloc(kk);
+        run_search(h, 1, (uint32_t)kk, h->d_ids.p, h->d_dist.p, st);
+        uint32_t cnt = 0;
+        HIP_CHECK(hipMemcpy(&cnt, h->d_count.p, 4, hipMemcpyDeviceToHost));
+        // the reference returns every result it found (<= max(k,1)); the caller's buffers
+        // hold max(k,1) entries
+        HIP_CHECK(hipMemcpy(ids, h->d_ids.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dist, h->d_dist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        *m = cnt;
+    });
+}
+
+// ---- hooks ---------------------------------------------------------------------------
+int cph_encode_query(cph_index* h, const float* query, uint8_t* lut, float* coeffs) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        Rotation local;
+        const Rotation* rot = &h->host.rot;
+        if (rot->D != h->D) { local.init(h->D, 42); rot = &local; }
+        std::vector<float> buf(h->D, 0.0f);
+        std::memcpy(buf.data(), query, h->dim * sizeof(float));
+        EncodedQuery eq;
+        encode_query(*rot, buf.data(), eq);
+        qu_to_lut(eq.qu.data(), h->D, lut);
+        coeffs[0] = eq.A; coeffs[1] = eq.B; coeffs[2] = eq.C;
+    });
+}
+
+int cph_entry_point(cph_index* h, const float* query, uint32_t* entry) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        std::vector<float> buf(h->D, 0.0f);
+        std::memcpy(buf.data(), query, h->dim * sizeof(float));
+        *entry = h->host.entry_point(buf.data());
+    });
+}
+
+int cph_fastscan_block(cph_index* h, const uint8_t* lut, const float* qparams, uint32_t vertex,
+                       float dist_qp_sq, float worst, int nn_full, uint32_t* sums, uint32_t* msb,
+                       float* est, float* lower, float* lower_stage1) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        if (vertex >= h->host.n) throw InvalidArg("vertex out of range");
+        h->use_device();
+        const uint32_t D = h->D, PW = h->L.PW;
+        std::vector<uint8_t> qu(D);
+        lut_to_qu(lut, D, qu.data());
+        std::vector<uint32_t> masks(PW * 4);
+        qu_to_masks(qu.data(), D, masks.data());
+        DevBuf<uint4> d_mask;
+        DevBuf<uint32_t> d_u;
+        DevBuf<float> d_f;
+        d_mask.alloc(PW);
+        d_u.alloc(64);
+        d_f.alloc(96);
+        HIP_CHECK(hipMemcpy(d_mask.p, masks.data(), PW * 16, hipMemcpyHostToDevice));
+        BlockHookArgs a{};
+        a.blk = h->d_blocks.p + (size_t)vertex * h->L.stride;
+        a.L = h->L;
+        a.qmask = d_mask.p;
+        a.qp = QP{qparams[0], qparams[1], qparams[2], qparams[3], qparams[4], qparams[5], qparams[6]};
+        a.dqp = dist_qp_sq;
+        a.worst = worst;
+        a.nn_full = nn_full;
+        a.sums = d_u.p; a.msb = d_u.p + 32;
+        a.est = d_f.p; a.lower = d_f.p + 32; a.lower1 = d_f.p + 64;
+        CPH_LAUNCH(block_hook_kernel, h->bits, D, dim3(1), dim3(64), (size_t)PW * 16, nullptr, a);
+        HIP_CHECK(hipDeviceSynchronize());
+        uint32_t hu[64];
+        float hf[96];
+        HIP_CHECK(hipMemcpy(hu, d_u.p, sizeof(hu), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hf, d_f.p, sizeof(hf), hipMemcpyDeviceToHost));
+        std::memcpy(sums, hu, 128); std::memcpy(msb, hu + 32, 128);
+        std::memcpy(est, hf, 128); std::memcpy(lower, hf + 32, 128);
+        std::memcpy(lower_stage1, hf + 64, 128);
+    });
+}
+
+int cph_exact_l2(cph_index* h, const float* query, const uint32_t* ids, uint64_t n, float* out) {
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        if (n == 0) return;
+        for (uint64_t i = 0; i < n; ++i)
+            if (ids[i] >= h->host.n) throw InvalidArg("id out of range");
+        h->use_device();
+        const uint32_t D = h->D;
+        std::vector<float> buf(D, 0.0f);
+        std::memcpy(buf.data(), query, h->dim * sizeof(float));
+        DevBuf<float> d_q, d_out;
+        DevBuf<uint32_t> d_i;
+        d_q.alloc(D); d_out.alloc(n); d_i.alloc(n);
+        HIP_CHECK(hipMemcpy(d_q.p, buf.data(), D * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_i.p, ids, n * 4, hipMemcpyHostToDevice));
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 7) / 8, 1024);
+        hipLaunchKernelGGL(exact_l2_hook_kernel, dim3(grid), dim3(64), (size_t)D * 4, nullptr, d_q.p,
+                           h->d_raw.p, h->d_norm.p, d_i.p, n, D, d_out.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(out, d_out.p, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"
+
+// ---- streaming FastScan benchmark object ---------------------------------------------------
+struct cph_stream {
+    int device = 0;
+    DevLayout L{};
+    RefLayout RL{};
+    uint64_t n_blocks = 0;
+    DevBuf<uint8_t> d_blocks;
+    DevBuf<uint4> d_mask;
+    DevBuf<float> d_sink;
+    std::vector<uint8_t> lut;
+    QP qp{};
+    float dqp = 0.0f;
+    int num_cus = 256;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+// Fills device-layout blocks with seeded random codes and consistent aux data.
+__global__ __launch_bounds__(64) void stream_fill_kernel(uint8_t* blocks, uint64_t n_blocks,
+                                                         DevLayout L, uint64_t seed) {
+    const int lane = threadIdx.x;
+    const int i = lane & 31, h = lane >> 5;
+    for (uint64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        uint8_t* blk = blocks + b * L.stride;
+        uint32_t pc[4] = {0, 0, 0, 0};  // popcount per plane of neighbour i (this lane's share)
+        const uint32_t T = L.BW * L.PW;
+        const uint32_t valid_bits = L.D >= 32 ? 32 : L.D;
+        const uint32_t vmask = valid_bits == 32 ? 0xFFFFFFFFu : ((1u << valid_bits) - 1u);
+        for (uint32_t t = h; t < T; t += 2) {  // the two lanes of a neighbour split its dwords
+            const uint32_t plane = t / L.PW;
+            uint32_t v = mix32(seed ^ (b * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)(t * 32 + i) << 20)) & vmask;
+            size_t off;
+            if (L.wide) {
+                const uint32_t ck = t / 4, e = t % 4;
+                const uint32_t hh = (L.NH == 2) ? ck / L.CPL : 0;
+                const uint32_t k = (L.NH == 2) ? ck % L.CPL : ck;
+                off = ((size_t)(k * L.NH * 32 + hh * 32 + i) * 16 + e * 4);
+            } else {
+                off = ((size_t)t * 32 + i) * 4;
+            }
+            *reinterpret_cast<uint32_t*>(blk + off) = v;
+            const uint32_t c = __popc(v);
+            if (plane == 0) pc[0] += c; else if (plane == 1) pc[1] += c;
+            else if (plane == 2) pc[2] += c; else pc[3] += c;
+        }
+        for (int p = 0; p < 4; ++p) pc[p] += __shfl_xor(pc[p], 32);
+        if (lane < 32) {
+            uint32_t wp = 0;
+            for (uint32_t p = 0; p < L.BW; ++p) wp += pc[p] << (L.BW - 1 - p);
+            const uint32_t r0 = mix32(seed ^ (b * 1315423911ULL) ^ (0x1000 + i));
+            const uint32_t r1 = mix32(seed ^ (b * 2654435761ULL) ^ (0x2000 + i));
+            const uint32_t r2 = mix32(seed ^ (b * 40503ULL) ^ (0x3000 + i));
+            float nop = 1.0f + 19.0f * (r0 >> 8) * (1.0f / 16777216.0f);
+            float ipqo = 0.5f + 0.4f * (r1 >> 8) * (1.0f / 16777216.0f);
+            float ipcp = -0.5f + (r2 >> 8) * (1.0f / 16777216.0f);
+            uint4 aux = make_uint4(__float_as_uint(nop), __float_as_uint(ipqo), __float_as_uint(ipcp),
+                                   (pc[0] & 0xFFFFu) | ((wp & 0xFFFFu) << 16));
+            reinterpret_cast<uint4*>(blk + L.aux_off)[i] = aux;
+            reinterpret_cast<uint32_t*>(blk + L.ids_off)[i] = mix32(seed ^ b ^ ((uint64_t)i << 40)) >> 1;
+            if (lane == 0) *reinterpret_cast<uint32_t*>(blk + L.count_off) = 32u;
+        }
+    }
+}
+
+void stream_launch(cph_stream* s, float* out_est, float* out_lower, uint64_t first, uint64_t count,
+                   hipStream_t st) {
+    StreamArgs a{};
+    a.blocks = s->d_blocks.p;
+    a.n_blocks = s->n_blocks;
+    a.L = s->L;
+    a.qmask = s->d_mask.p;
+    a.qp = s->qp;
+    a.dqp = s->dqp;
+    a.sink = s->d_sink.p;
+    a.out_est = out_est;
+    a.out_lower = out_lower;
+    a.first = first;
+    a.count = count;
+    const uint32_t grid = (uint32_t)s->num_cus * 8;
+    CPH_LAUNCH(fastscan_stream_kernel, s->L.BW, s->L.D, dim3(grid), dim3(256), (size_t)s->L.PW * 16, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cph_fastscan_stream_create(int device, uint32_t D, uint32_t bits, uint64_t n_blocks,
+                               uint64_t seed, cph_stream** out, uint64_t* block_bytes) {
+    return guarded([&] {
+        *out = nullptr;
+        if (bits != 1 && bits != 2 && bits != 4) throw InvalidArg("bits must be 1, 2 or 4");
+        if (D < 16 || D > 2048 || (D & (D - 1))) throw InvalidArg("D must be a power of two in 16..2048");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw std::runtime_error("No HIP device available: the MI355X path has no CPU fallback.");
+        HIP_CHECK(hipSetDevice(device));
+        auto s = std::unique_ptr<cph_stream>(new cph_stream());
+        s->device = device;
+        s->L = make_dev_layout(D, bits);
+        s->RL = make_ref_layout(D, bits);
+        s->n_blocks = n_blocks;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
+        s->d_blocks.alloc(n_blocks * s->L.stride + 64);
+        s->d_mask.alloc(s->L.PW);
+        s->d_sink.alloc((size_t)s->num_cus * 8 * 4);
+        hipLaunchKernelGGL(stream_fill_kernel, dim3(s->num_cus * 16), dim3(64), 0, nullptr,
+                           s->d_blocks.p, n_blocks, s->L, seed);
+        HIP_CHECK(hipGetLastError());
+        // one seeded query: random rotated vector -> 4-bit scalars -> masks / LUT / coefficients
+        std::mt19937_64 rng(seed * 7919 + 13);
+        std::normal_distribution<float> nd(0.0f, 1.0f);
+        std::vector<float> q(D);
+        for (auto& x : q) x = nd(rng);
+        Rotation rot;
+        rot.init(D, 42);
+        EncodedQuery eq;
+        encode_query(rot, q.data(), eq);
+        s->lut.resize(D / 4 * 16);
+        qu_to_lut(eq.qu.data(), D, s->lut.data());
+        std::vector<uint32_t> masks(s->L.PW * 4);
+        qu_to_masks(eq.qu.data(), D, masks.data());
+        HIP_CHECK(hipMemcpy(s->d_mask.p, masks.data(), masks.size() * 4, hipMemcpyHostToDevice));
+        s->qp = QP{eq.A, eq.B, eq.C, 1.0f, 0.0f, 0.0f, 0.05f};
+        s->dqp = 140.0f;
+        HIP_CHECK(hipEventCreate(&s->ev0));
+        HIP_CHECK(hipEventCreate(&s->ev1));
+        HIP_CHECK(hipDeviceSynchronize());
+        if (block_bytes) *block_bytes = s->L.stride;
+        *out = s.release();
+    });
+}
+
+int cph_fastscan_stream_run(cph_stream* s, int reps, double* avg_ms, double* checksum) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        if (reps < 1) reps = 1;
+        hipStream_t st = nullptr;
+        HIP_CHECK(hipEventRecord(s->ev0, st));
+        for (int r = 0; r < reps; ++r) stream_launch(s, nullptr, nullptr, 0, 0, st);
+        HIP_CHECK(hipEventRecord(s->ev1, st));
+        HIP_CHECK(hipEventSynchronize(s->ev1));
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        if (avg_ms) *avg_ms = (double)ms / reps;
+        if (checksum) {
+            std::vector<float> sink(s->d_sink.n);
+            HIP_CHECK(hipMemcpy(sink.data(), s->d_sink.p, sink.size() * 4, hipMemcpyDeviceToHost));
+            double t = 0.0;
+            for (float x : sink) t += x;
+            *checksum = t;
+        }
+    });
+}
+
+int cph_fastscan_stream_export(cph_stream* s, uint64_t first, uint64_t count, uint8_t* ref_blocks,
+                               uint8_t* lut, float* qparams, float* dist_qp_sq) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        if (first + count > s->n_blocks) throw InvalidArg("block range out of bounds");
+        if (count && ref_blocks) {
+            std::vector<uint8_t> dev(count * s->L.stride);
+            HIP_CHECK(hipMemcpy(dev.data(), s->d_blocks.p + first * s->L.stride, dev.size(),
+                                hipMemcpyDeviceToHost));
+            parallel_for(count, 1024, [&](size_t lo, size_t hi) {
+                for (size_t b = lo; b < hi; ++b)
+                    repack_dev_to_ref(&dev[b * s->L.stride], s->L, s->RL, ref_blocks + b * s->RL.nb_bytes);
+            });
+        }
+        if (lut) std::memcpy(lut, s->lut.data(), s->lut.size());
+        if (qparams) {
+            qparams[0] = s->qp.A; qparams[1] = s->qp.B; qparams[2] = s->qp.C;
+            qparams[3] = s->qp.affine_a; qparams[4] = s->qp.affine_b; qparams[5] = s->qp.floor;
+            qparams[6] = s->qp.slack;
+        }
+        if (dist_qp_sq) *dist_qp_sq = s->dqp;
+    });
+}
+
+int cph_fastscan_stream_eval(cph_stream* s, uint64_t first, uint64_t count, float* est, float* lower) {
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(s->device));
+        if (first + count > s->n_blocks) throw InvalidArg("block range out of bounds");
+        if (!count) return;
+        DevBuf<float> d_e, d_l;
+        d_e.alloc(count * 32);
+        d_l.alloc(count * 32);
+        stream_launch(s, d_e.p, d_l.p, first, count, nullptr);
+        HIP_CHECK(hipMemcpy(est, d_e.p, count * 128, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(lower, d_l.p, count * 128, hipMemcpyDeviceToHost));
+    });
+}
+
+int cph_fastscan_stream_destroy(cph_stream* s) {
+    return guarded([&] {
+        if (!s) return;
+        (void)hipSetDevice(s->device);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+        delete s;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+// device_fastscan.h — wave-level FastScan RaBitQ estimator for gfx950 (wave64).
+//
+// Replaces, on the GPU, the reference's AVX2 kernels in distance/fastscan_kernel.hpp:
+//   compute_inner_products            :17-87     one bit-plane, 32 neighbours
+//   compute_msb_only_inner_products   :349-368   2*S0 + S1
+//   compute_nbit_inner_products       :197-217   sum_b 2^(BW-1-b) * S_b, and S0
+//   convert_to_distances_with_bounds  :89-194    1-bit epilogue
+//   convert_msb_to_lower_bounds       :371-425   stage-1 lower bound
+//   convert_nbit_to_distances_with_bounds :220-346  N-bit epilogue
+//
+// Formulation.  The reference's LUT holds, per 4-dim segment, every subset sum of the
+// query's 4-bit scalars q_u (encoder/rabitq_encoder.hpp:119-130), and VPSHUFB gathers
+// lut[seg][code nibble].  Summed over segments this is exactly  S_b = sum_d q_u[d] *
+// bit_b[d].  With the query scalars bit-sliced into four D-bit masks Q_j (bit j of q_u),
+//      S_b = sum_j 2^j * popcount(code_plane_b AND Q_j)
+// — the identical integer, computed with v_and + v_bcnt on 32 dims per instruction, no
+// per-lane table gather.  The query masks (16 B per 32 dims) sit in LDS and are read as
+// wave-uniform broadcasts.  One wave handles one vertex' 32-neighbour block: lane
+// (h = lane>>5, i = lane&31) owns half of neighbour i's code dwords, so each load
+// instruction of the wave reads 1 KiB contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cph_core.h"
+
+namespace cph {
+
+struct QP {  // RaBitQQuery scalars (core/codes.hpp:79-93)
+    float A, B, C, affine_a, affine_b, floor, slack;
+};
+
+struct LaneEst {      // per-lane (neighbour i = lane & 31) results, valid on all 64 lanes
+    uint32_t nbit;    // 1-bit: plane sum; N-bit: weighted N-bit sum
+    uint32_t msb;     // plane-0 sum S0
+    uint32_t msb2;    // 2*S0 + S1 (BW >= 2), S0 (BW == 1)
+    float nop, ip_qo, ip_cp;
+    uint32_t pop, wpop;
+};
+
+__device__ __forceinline__ float vmaxf(float a, float b) { return a > b ? a : b; }  // _mm256_max_ps
+__device__ __forceinline__ float vminf(float a, float b) { return a < b ? a : b; }  // _mm256_min_ps
+
+__device__ __forceinline__ void acc4(uint32_t c, uint4 q, uint32_t& a0, uint32_t& a1,
+                                     uint32_t& a2, uint32_t& a3) {
+    a0 += __popc(c & q.x);
+    a1 += __popc(c & q.y);
+    a2 += __popc(c & q.z);
+    a3 += __popc(c & q.w);
+}
+
+// Integer sums of one block.  qm = LDS, uint4 per 32-dim word: {Q0,Q1,Q2,Q3}.
+// SD = compile-time D (0 = runtime D from the layout).
+template <int BW, int SD>
+__device__ __forceinline__ void block_sums(const uint8_t* __restrict__ blk, const DevLayout& L,
+                                           const uint4* qm, int lane, uint32_t& nbit,
+                                           uint32_t& msb, uint32_t& msb2) {
+    const int h = lane >> 5;
+    const uint32_t PW = SD ? (SD >= 32 ? SD / 32 : 1) : L.PW;
+    const bool wide = SD ? (SD >= 128) : (L.wide != 0);
+    if (wide) {
+        const uint4* cp = reinterpret_cast<const uint4*>(blk) + lane;
+        if constexpr (BW >= 2) {
+            constexpr int PPH = BW / 2;  // planes per lane half (NH == 2 always here)
+            const uint32_t G = PW >> 2;  // 16-B chunks per plane
+            uint32_t S[PPH];
+#pragma unroll
+            for (int pl = 0; pl < PPH; ++pl) {
+                uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 2
+                for (uint32_t g = 0; g < G; ++g) {
+                    uint4 c = cp[(pl * G + g) * 64];
+                    acc4(c.x, qm[4 * g + 0], a0, a1, a2, a3);
+                    acc4(c.y, qm[4 * g + 1], a0, a1, a2, a3);
+                    acc4(c.z, qm[4 * g + 2], a0, a1, a2, a3);
+                    acc4(c.w, qm[4 * g + 3], a0, a1, a2, a3);
+                }
+                S[pl] = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+            }
+            // plane b = h*PPH + pl carries weight 2^(BW-1-b)
+            uint32_t part = 0;
+#pragma unroll
+            for (int pl = 0; pl < PPH; ++pl) part += S[pl] << (BW - 1 - (h * PPH + pl));
+            uint32_t other = __shfl_xor(part, 32);
+            nbit = part + other;
+            uint32_t s0_other = __shfl_xor(S[0], 32);
+            if constexpr (BW == 2) {
+                uint32_t s0 = h ? s0_other : S[0];
+                uint32_t s1 = h ? S[0] : s0_other;
+                msb = s0;
+                msb2 = 2 * s0 + s1;
+            } else {
+                uint32_t s1_other = __shfl_xor(S[1], 32);
+                uint32_t s0 = h ? s0_other : S[0];
+                uint32_t s1 = h ? s1_other : S[1];
+                msb = s0;
+                msb2 = 2 * s0 + s1;
+            }
+        } else {
+            const uint32_t NH = SD ? ((SD / 32) / 4 >= 2 ? 2 : 1) : L.NH;
+            const uint32_t CPL = SD ? ((SD / 32) / 4 / NH) : L.CPL;
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if ((uint32_t)h < NH) {
+                const uint4* cq = reinterpret_cast<const uint4*>(blk) + (lane & (NH * 32 - 1));
+#pragma unroll 2
+                for (uint32_t k = 0; k < CPL; ++k) {
+                    uint4 c = cq[k * NH * 32];
+                    uint32_t w0 = (h * CPL + k) * 4;
+                    acc4(c.x, qm[w0 + 0], a0, a1, a2, a3);
+                    acc4(c.y, qm[w0 + 1], a0, a1, a2, a3);
+                    acc4(c.z, qm[w0 + 2], a0, a1, a2, a3);
+                    acc4(c.w, qm[w0 + 3], a0, a1, a2, a3);
+                }
+            }
+            uint32_t s = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+            uint32_t o = __shfl_xor(s, 32);
+            s = (NH == 2) ? s + o : (h ? o : s);
+            nbit = msb = msb2 = s;
+        }
+    } else {
+        // small D (16/32/64): dwords ordered [plane*PW + w][neighbour]; both lane halves
+        // compute their neighbour redundantly.
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(blk) + (lane & 31);
+        uint32_t S[BW];
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (uint32_t w = 0; w < PW; ++w) acc4(cw[(b * PW + w) * 32], qm[w], a0, a1, a2, a3);
+            S[b] = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+        }
+        uint32_t t = 0;
+#pragma unroll
+        for (int b = 0; b < BW; ++b) t += S[b] << (BW - 1 - b);
+        nbit = t;
+        msb = S[0];
+        if constexpr (BW >= 2) msb2 = 2 * S[0] + S[1]; else msb2 = S[0];
+    }
+}
+
+template <int BW, int SD>
+__device__ __forceinline__ void load_block(const uint8_t* __restrict__ blk, const DevLayout& L,
+                                           const uint4* qm, int lane, LaneEst& o) {
+    const uint4 aux = reinterpret_cast<const uint4*>(blk + L.aux_off)[lane & 31];
+    block_sums<BW, SD>(blk, L, qm, lane, o.nbit, o.msb, o.msb2);
+    o.nop = __uint_as_float(aux.x);
+    o.ip_qo = __uint_as_float(aux.y);
+    o.ip_cp = __uint_as_float(aux.z);
+    o.pop = aux.w & 0xFFFFu;
+    o.wpop = aux.w >> 16;
+}
+
+// Shared tail of the AVX2 vector paths fastscan_kernel.hpp:148-169 / :287-317.
+__device__ __forceinline__ void est_and_lower(const QP& q, float ip_est_approx, float ip_lb_approx,
+                                              float nop, float ip_qo, float ip_cp, float dqp,
+                                              float sqrt_dqp, float& est, float& lower) {
+    float ipq = vmaxf(ip_qo, q.floor);
+    bool good = ipq > kEpsMedium;
+    float e = good ? (ip_est_approx - ip_cp) / ipq : 0.0f;
+    e = __fmaf_rn(q.affine_a, e, q.affine_b);
+    float dist = __fmaf_rn(nop, nop, dqp);
+    dist = __fmaf_rn(-(2.0f * nop), e, dist);
+    est = vmaxf(dist, 0.0f);
+    float m = good ? (ip_lb_approx - ip_cp) / ipq : 0.0f;
+    m = __fmaf_rn(q.affine_a, m, q.affine_b);
+    float cosu = (m + q.slack) / vmaxf(sqrt_dqp, kEpsMedium);
+    cosu = vminf(vmaxf(cosu, -1.0f), 1.0f);
+    float lo = __fmaf_rn(nop, nop, dqp);
+    lo = __fmaf_rn(-((2.0f * nop) * sqrt_dqp), cosu, lo);
+    lo = vmaxf(lo, 0.0f);
+    lower = good ? lo : 0.0f;
+}
+
+// Stage-1 lower bound, op-for-op as the compiled reference evaluates
+// convert_msb_to_lower_bounds (fastscan_kernel.hpp:403-424; see oracle/cph_oracle.cpp).
+template <int BW>
+__device__ __forceinline__ float stage1_lower(const QP& q, const LaneEst& v, float dqp,
+                                              float sqrt_dqp) {
+    if (dqp < kEpsSmall) return 0.0f;
+    const float invk = (BW >= 2) ? (1.0f / 3.0f) : 1.0f;
+    float A = q.A * invk, B = q.B * invk;
+    float ipq = (v.ip_qo < q.floor) ? q.floor : v.ip_qo;
+    if (ipq <= kEpsMedium) return 0.0f;
+    float ipa = __fmaf_rn(B, (float)v.pop, A * (float)v.msb2) + q.C;
+    float e = (ipa - v.ip_cp) / ipq;
+    e = __fmaf_rn(e, q.affine_a, q.affine_b);
+    float c = (e + q.slack) / sqrt_dqp;
+    c = (c < -1.0f) ? -1.0f : ((1.0f < c) ? 1.0f : c);
+    float lo = __fmaf_rn(-c, (v.nop + v.nop) * sqrt_dqp, __fmaf_rn(v.nop, v.nop, dqp));
+    return (lo < 0.0f) ? 0.0f : lo;
+}
+
+// Stage-2 (full) estimate + lower bound.
+template <int BW>
+__device__ __forceinline__ void stage2_est(const QP& q, const LaneEst& v, float dqp,
+                                           float sqrt_dqp, float& est, float& lower) {
+    if (dqp < kEpsSmall) {  // fastscan_kernel.hpp:112-119 / :249-256 (scalar, fused by GCC)
+        est = __fmaf_rn(v.nop, v.nop, dqp);
+        lower = 0.0f;
+        return;
+    }
+    if constexpr (BW == 1) {
+        float ipa = __fmaf_rn(q.A, (float)v.nbit, __fmaf_rn(q.B, (float)v.pop, q.C));
+        est_and_lower(q, ipa, ipa, v.nop, v.ip_qo, v.ip_cp, dqp, sqrt_dqp, est, lower);
+    } else {
+        constexpr float K = (float)((1u << BW) - 1);
+        constexpr float invK = 1.0f / K;
+        float An = q.A * invK, Bn = q.B * invK;
+        float ipn = __fmaf_rn(An, (float)v.nbit, __fmaf_rn(Bn, (float)v.wpop, q.C));
+        float ipm = __fmaf_rn(q.A, (float)v.msb, __fmaf_rn(q.B, (float)v.pop, q.C));
+        est_and_lower(q, ipn, ipm, v.nop, v.ip_qo, v.ip_cp, dqp, sqrt_dqp, est, lower);
+    }
+}
+
+// ---- exact arithmetic: core/memory.hpp:65-95 -----------------------------------------
+// 8 FMA chains (chain j = elements j, j+8, ...) on the 8 lanes of a lane group, then
+// ((c0+c4)+(c1+c5)) + ((c2+c6)+(c3+c7)) via xor-4, xor-1, xor-2 exchanges (fp add is
+// commutative, so every lane of the group ends with the same bits).
+__device__ __forceinline__ float group_reduce8(float c) {
+    float a = c + __shfl_xor(c, 4);
+    float b = a + __shfl_xor(a, 1);
+    return b + __shfl_xor(b, 2);
+}
+
+// dot(q, v): q in LDS, v a global row; j = lane & 7.
+__device__ __forceinline__ float group_dot8(const float* q_lds, const float* __restrict__ v,
+                                             uint32_t D, int j) {
+    float c = 0.0f;
+#pragma unroll 4
+    for (uint32_t i = j; i < D; i += 8) c = __fmaf_rn(q_lds[i], v[i], c);
+    return group_reduce8(c);
+}
+
+// sum (q - v)^2 with the same chain structure (l2_distance_simd, core/memory.hpp:65-79).
+__device__ __forceinline__ float group_l2sq8(const float* q_lds, const float* __restrict__ v,
+                                              uint32_t D, int j) {
+    float c = 0.0f;
+#pragma unroll 4
+    for (uint32_t i = j; i < D; i += 8) {
+        float d = q_lds[i] - v[i];
+        c = __fmaf_rn(d, d, c);
+    }
+    return group_reduce8(c);
+}
+
+// search/rabitq_search.hpp:90-93
+__device__ __forceinline__ float exact_from_dot(float qnorm, float norm, float dot) {
+    float v = (qnorm + norm) - 2.0f * dot;
+    return (v < 0.0f) ? 0.0f : v;  // std::max(v, 0.0f)
+}
+
+}  // namespace cph

@@ -1,0 +1,455 @@
+// device_search.h — persistent layer-0 beam search, one wavefront per query.
+//
+// GPU counterpart of rabitq_search::search (search/rabitq_search.hpp:60-277) and its
+// helpers BoundedMaxHeap (:17-49) / BeamEntry (:53-58).  Results are bit-identical to the
+// reference: the data-parallel parts (FastScan block, estimated-set probes, speculative
+// exact L2 of every lane whose estimate beats the threshold at loop entry) run on all 64
+// lanes, while the order-dependent decisions of the 32-neighbour loop (:218-273) are
+// replayed by lane 0 in neighbour order with the reference's heap algorithms
+// (std::push_heap / pop_heap / sort_heap element movement, so ties break identically).
+//
+// Observations that shape the kernel:
+//  * every node enters the beam at most once (each push is guarded by the estimated-set
+//    test), so the reference's second "visited" table is never observable — only the
+//    estimated set is kept (a per-slot bitmap, cleared by un-marking the logged ids);
+//  * in a non-warm-up expansion the result-heap threshold only decreases, so
+//    {est < worst at loop entry} is a superset of the lanes the serial loop will rerank.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cph_core.h"
+#include "device_fastscan.h"
+
+namespace cph {
+
+struct Result {
+    uint32_t id;
+    float dist;
+};
+
+struct SearchArgs {
+    // index
+    const uint8_t* blocks;
+    const float* raw;       // [n][D]
+    const float* norm_sq;   // [n]
+    uint64_t n;
+    DevLayout L;
+    uint32_t flags;         // bit 0: some vertex repeats a neighbour id
+    // encoded queries
+    const float* queries;   // [nq][D] zero-padded
+    const uint4* qmasks;    // [nq][PW]
+    const QueryHeader* qhdr;
+    const uint32_t* todo;   // optional: query indices to run (re-run list), else 0..nq-1
+    uint32_t nq;
+    uint32_t k;
+    SearchConsts sc;
+    // work queue + per-slot scratch
+    uint32_t* counter;
+    uint64_t cap;           // per-slot log/heap capacity
+    uint64_t bm_words;      // per-slot bitmap words
+    uint32_t* bitmaps;
+    uint2* heaps;           // {est bits, log slot}
+    uint32_t* log_ids;      // every newly estimated id, in discovery order
+    float* lowers;          // lower bound of pushed entries, indexed by log slot
+    // outputs
+    int64_t* out_ids;       // [nq][k]
+    float* out_dist;        // [nq][k]
+    uint32_t* out_count;    // [nq]
+    uint32_t* status;       // [nq]
+    unsigned long long* stats;  // [8]
+};
+
+// ---- libstdc++-compatible binary heaps ------------------------------------------------
+// Result heap: max-heap on dist (std::less via SearchResult::operator<, core/types.hpp:16).
+__device__ __forceinline__ void nn_sift_up(Result* h, uint32_t hole, uint32_t top, Result v) {
+    while (hole > top) {
+        uint32_t p = (hole - 1) >> 1;
+        Result pv = h[p];
+        if (!(pv.dist < v.dist)) break;
+        h[hole] = pv;
+        hole = p;
+    }
+    h[hole] = v;
+}
+__device__ __forceinline__ void nn_adjust(Result* h, uint32_t hole, uint32_t len, Result v) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        Result r = h[child], l = h[child - 1];
+        if (r.dist < l.dist) { --child; r = l; }
+        h[hole] = r;
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    nn_sift_up(h, hole, top, v);
+}
+// BoundedMaxHeap::push, rabitq_search.hpp:26-35
+__device__ __forceinline__ void nn_push(Result* h, uint32_t& size, uint32_t k, Result r) {
+    if (size < k) {
+        nn_sift_up(h, size, 0, r);
+        ++size;
+    } else if (r.dist < h[0].dist) {
+        if (size > 1) {
+            Result v = h[size - 1];
+            nn_adjust(h, 0, size - 1, v);   // pop_heap
+        }
+        nn_sift_up(h, size - 1, 0, r);      // back() = r; push_heap
+    }
+}
+__device__ __forceinline__ void nn_sort(Result* h, uint32_t size) {  // std::sort_heap
+    while (size > 1) {
+        Result v = h[size - 1];
+        h[size - 1] = h[0];
+        nn_adjust(h, 0, size - 1, v);
+        --size;
+    }
+}
+
+// Beam: std::priority_queue<BeamEntry, vector, greater> — a heap whose comparator is
+// "a.est > b.est" (rabitq_search.hpp:57,79-80).  Entries are {est bits, log slot}.
+__device__ __forceinline__ void beam_sift_up(uint2* h, uint32_t hole, uint32_t top, uint2 v) {
+    const float vk = __uint_as_float(v.x);
+    while (hole > top) {
+        uint32_t p = (hole - 1) >> 1;
+        uint2 pv = h[p];
+        if (!(__uint_as_float(pv.x) > vk)) break;
+        h[hole] = pv;
+        hole = p;
+    }
+    h[hole] = v;
+}
+__device__ __forceinline__ void beam_adjust(uint2* h, uint32_t hole, uint32_t len, uint2 v) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        uint2 r = h[child], l = h[child - 1];
+        if (__uint_as_float(r.x) > __uint_as_float(l.x)) { --child; r = l; }
+        h[hole] = r;
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        h[hole] = h[child - 1];
+        hole = child - 1;
+    }
+    beam_sift_up(h, hole, top, v);
+}
+
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ float bcast_f32(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+
+// LDS carve-up (bytes): qm[PW*16] | qv[D*4] | nn[k*8] | est[128] lower[128] exact[128]
+// ids[128] list[32] pad
+__host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
+    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64;
+}
+
+template <int BW, int SD>
+__global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int li = lane & 31;
+    const uint32_t D = SD ? SD : a.L.D;
+    const uint32_t PW = SD ? (SD >= 32 ? SD / 32 : 1) : a.L.PW;
+    const uint32_t k = a.k;
+    uint4* qm = reinterpret_cast<uint4*>(smem);
+    float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
+    Result* nn = reinterpret_cast<Result*>(smem + (size_t)PW * 16 + (size_t)D * 4);
+    float* s_est = reinterpret_cast<float*>(smem + (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8);
+    float* s_lower = s_est + 32;
+    float* s_exact = s_lower + 32;
+    uint32_t* s_ids = reinterpret_cast<uint32_t*>(s_exact + 32);
+    uint8_t* s_list = reinterpret_cast<uint8_t*>(s_ids + 32);
+
+    const uint32_t slot = blockIdx.x;
+    uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
+    uint2* heap = a.heaps + (size_t)slot * a.cap;
+    uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
+    float* lowers = a.lowers + (size_t)slot * a.cap;
+    const float FMAX = 3.402823466e+38f;
+
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.counter, 1u);
+        t = bcast_u32(t);
+        if (t >= a.nq) break;
+        const uint32_t qi = a.todo ? a.todo[t] : t;
+
+        for (uint32_t w = lane; w < PW; w += 64) qm[w] = a.qmasks[(size_t)qi * PW + w];
+        for (uint32_t d = lane; d < D; d += 64) qv[d] = a.queries[(size_t)qi * D + d];
+        const QueryHeader hd = a.qhdr[qi];
+        __syncthreads();
+
+        QP qp;
+        qp.A = hd.A; qp.B = hd.B; qp.C = hd.C;
+        qp.affine_a = a.sc.affine_a; qp.affine_b = a.sc.affine_b; qp.floor = a.sc.ip_qo_floor;
+        qp.slack = a.sc.slack[0];
+        const float gamma = a.sc.gamma;
+
+        // query_norm_sq = dot(q, q)  (:88)
+        float qnorm;
+        {
+            float c = 0.0f;
+            for (uint32_t i = lane & 7; i < D; i += 8) c = __fmaf_rn(qv[i], qv[i], c);
+            qnorm = group_reduce8(c);
+        }
+
+        // lane-0 serial state
+        uint32_t beam_size = 0, nn_size = 0;
+        float gamma_q = gamma;
+        double ratio_sum = 0.0, ratio_sq_sum = 0.0;
+        unsigned long long ratio_count = 0;
+        // uniform state
+        uint32_t log_count = 0;
+        int slack_batch = 0;
+        bool overflow = false;
+        unsigned long long st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
+
+        // entry: ep_est = exact_l2(ep); beam.push({ep_est, 0, ep}); mark estimated (:95-97)
+        {
+            const uint32_t ep = hd.entry;
+            float dot = group_dot8(qv, a.raw + (size_t)ep * D, D, lane & 7);
+            float ex = exact_from_dot(qnorm, a.norm_sq[ep], dot);
+            st_exact++;
+            if (lane == 0) {
+                logi[0] = ep;
+                lowers[0] = 0.0f;
+                heap[0] = make_uint2(__float_as_uint(ex), 0u);
+                beam_size = 1;
+                atomicOr(&bm[ep >> 5], 1u << (ep & 31));
+            }
+            log_count = 1;
+        }
+        __syncthreads();
+
+        for (;;) {
+            // ---- pop + termination tests (lane 0) (:106-122) --------------------------
+            uint32_t state = 0;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
+            uint32_t cur_id = 0;
+            if (lane == 0) {
+                if (beam_size > 0) {
+                    uint2 top = heap[0];
+                    if (beam_size > 1) {
+                        uint2 v = heap[beam_size - 1];
+                        beam_adjust(heap, 0, beam_size - 1, v);
+                    }
+                    --beam_size;
+                    float cur_est = __uint_as_float(top.x);
+                    cur_id = logi[top.y];
+                    float cur_lower = lowers[top.y];
+                    float worst = nn_size ? nn[0].dist : FMAX;
+                    if (nn_size >= k && cur_est >= gamma_q * worst) state = 0;
+                    else if (nn_size >= k && cur_lower > worst) state = 1;
+                    else state = 2;
+                }
+            }
+            state = bcast_u32(state);
+            if (state == 0) break;
+            if (state == 1) continue;
+            cur_id = bcast_u32(cur_id);
+
+            // ---- exact distance of the popped node; nn.push (:130-133) ----------------
+            const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
+            LaneEst v;
+            load_block<BW, SD>(blk, a.L, qm, lane, v);
+            const uint32_t nid = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
+            const uint32_t count = *reinterpret_cast<const uint32_t*>(blk + a.L.count_off);
+            float exact_dist;
+            {
+                float dot = group_dot8(qv, a.raw + (size_t)cur_id * D, D, lane & 7);
+                exact_dist = exact_from_dot(qnorm, a.norm_sq[cur_id], dot);
+            }
+            st_exact++;
+            st_exp++;
+            if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
+            const uint32_t nn_sz = bcast_u32(nn_size);
+            float worst0;
+            {
+                float w = 0.0f;
+                if (lane == 0) w = nn_size ? nn[0].dist : FMAX;
+                worst0 = bcast_f32(w);
+            }
+            if (count == 0) continue;  // (:137)
+
+            // slack level schedule (:141-145)
+            if (a.sc.num_slack > 0) {
+                int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
+                qp.slack = a.sc.slack[lvl];
+                ++slack_batch;
+            }
+            const float dqp = exact_dist;
+            const float sq = __fsqrt_rn(dqp);
+
+            // ---- FastScan estimates (:159-206) ----------------------------------------
+            float est, lower;
+            if constexpr (BW == 1) {
+                stage2_est<1>(qp, v, dqp, sq, est, lower);
+            } else {
+                float lo1 = stage1_lower<BW>(qp, v, dqp, sq);
+                bool surv = (nn_sz < k) || (li < (int)count && lo1 < worst0);
+                if (__any(surv)) {
+                    stage2_est<BW>(qp, v, dqp, sq, est, lower);
+                } else {
+                    est = FMAX;
+                    lower = lo1;
+                    st_skip++;
+                }
+            }
+
+            // ---- estimated set: test-and-set in neighbour order (:227) ----------------
+            const bool active = lane < 32 && (uint32_t)lane < count;
+            bool is_new = false;
+            if (active) {
+                uint32_t bit = 1u << (nid & 31);
+                uint32_t old = atomicOr(&bm[nid >> 5], bit);
+                is_new = (old & bit) == 0;
+            }
+            // a vertex whose neighbour list repeats an id: only the first copy is new
+            if ((a.flags & 1u) && __any(is_new)) {
+                // (graphs written by the reference never repeat an id; the loader sets the
+                // flag when one does, and only then is this screen paid for)
+                for (int j = 0; j < 31; ++j) {
+                    uint32_t oj = __shfl(nid, j);
+                    bool nj = __shfl((int)is_new, j) != 0;
+                    if (nj && lane > j && lane < 32 && oj == nid) is_new = false;
+                }
+            }
+            const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
+            const bool warmup = nn_sz < k;  // (:210)
+            bool cand = is_new && (warmup || (lower < worst0 && est < worst0));
+            const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
+
+            // log new ids (discovery order = neighbour order)
+            const uint32_t n_new = __popc(new_mask);
+            const uint32_t my_rank = __popc(new_mask & ((1u << li) - 1u));
+            if (log_count + n_new > a.cap) { overflow = true; break; }
+            if (is_new) logi[log_count + my_rank] = nid;
+            if (lane < 32) {
+                s_est[lane] = est;
+                s_lower[lane] = lower;
+                s_ids[lane] = nid;
+            }
+            if (cand) s_list[__popc(cand_mask & ((1u << li) - 1u))] = (uint8_t)lane;
+            st_new += n_new;
+            __syncthreads();
+
+            // ---- speculative exact L2 of the candidates, 8 per pass -------------------
+            {
+                const uint32_t n_cand = __popc(cand_mask);
+                const int g = lane >> 3;
+                for (uint32_t base = 0; base < n_cand; base += 8) {
+                    const bool have = base + g < n_cand;
+                    const uint32_t idx = have ? s_list[base + g] : 0;
+                    const uint32_t cid = have ? s_ids[idx] : cur_id;
+                    float dot = group_dot8(qv, a.raw + (size_t)cid * D, D, lane & 7);
+                    float ex = exact_from_dot(qnorm, a.norm_sq[cid], dot);
+                    if (have && (lane & 7) == 0) s_exact[idx] = ex;
+                }
+                st_exact += n_cand;
+            }
+            __syncthreads();
+
+            // ---- serial replay of the neighbour loop (:218-273), lane 0 ---------------
+            if (lane == 0) {
+                uint32_t m = new_mask;
+                while (m) {
+                    const int i = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const uint32_t lslot = log_count + __popc(new_mask & ((1u << i) - 1u));
+                    const uint32_t id_i = s_ids[i];
+                    float worst = nn_size ? nn[0].dist : FMAX;
+                    const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
+                    float key, lo;
+                    bool push = false;
+                    if (warmup) {
+                        const float ex = s_exact[i];
+                        nn_push(nn, nn_size, k, Result{id_i, ex});
+                        if (ex < dabs) { push = true; key = ex; lo = ex; }
+                    } else {
+                        const float e = s_est[i];
+                        lo = s_lower[i];
+                        if (lo >= worst) continue;
+                        if (e < worst) {
+                            const float ex = s_exact[i];
+                            nn_push(nn, nn_size, k, Result{id_i, ex});
+                            if (ex < dabs) { push = true; key = ex; }
+                            if (ex > kEpsSmall) {
+                                // gamma adaptation (:255-267), fused as the reference compiles it
+                                double r = (double)(e / ex);
+                                ratio_sum += r;
+                                ratio_sq_sum = fma(r, r, ratio_sq_sum);
+                                ++ratio_count;
+                                if (ratio_count >= a.sc.gamma_warmup) {
+                                    double cnt = (double)ratio_count;
+                                    double mean = ratio_sum / cnt;
+                                    double var = fma(-mean, mean, ratio_sq_sum / cnt);
+                                    double sd = sqrt(var < 0.0 ? 0.0 : var);
+                                    float gq = gamma * (float)fma((double)a.sc.gamma_beta, sd, 1.0);
+                                    gamma_q = (gq < gamma) ? gamma
+                                                           : ((a.sc.gamma_max < gq) ? a.sc.gamma_max : gq);
+                                }
+                            }
+                        } else if (e < dabs) {
+                            push = true;
+                            key = e;
+                        }
+                    }
+                    if (push) {
+                        lowers[lslot] = lo;
+                        beam_sift_up(heap, beam_size, 0, make_uint2(__float_as_uint(key), lslot));
+                        ++beam_size;
+                        ++st_push;
+                    }
+                }
+            }
+            log_count += n_new;
+            __syncthreads();
+        }
+
+        // ---- results (:276; src/bindings.cpp:202-210) ----------------------------------
+        if (lane == 0 && !overflow) nn_sort(nn, nn_size);
+        const uint32_t nn_final = bcast_u32(nn_size);
+        __syncthreads();
+        if (!overflow) {
+            for (uint32_t j = lane; j < k; j += 64) {
+                if (j < nn_final) {
+                    a.out_ids[(size_t)qi * k + j] = (int64_t)nn[j].id;
+                    a.out_dist[(size_t)qi * k + j] = nn[j].dist;
+                } else {
+                    a.out_ids[(size_t)qi * k + j] = -1;
+                    a.out_dist[(size_t)qi * k + j] = FMAX;
+                }
+            }
+        }
+        if (lane == 0) {
+            a.out_count[qi] = nn_final;
+            a.status[qi] = overflow ? kStatusOverflow : kStatusOk;
+            atomicAdd(&a.stats[0], st_exp);
+            atomicAdd(&a.stats[1], st_exact);
+            atomicAdd(&a.stats[2], st_new);
+            atomicAdd(&a.stats[3], st_push);
+            atomicAdd(&a.stats[4], st_skip);
+            if (overflow) atomicAdd(&a.stats[5], 1ull);
+        }
+        // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --
+        __syncthreads();
+        if (overflow) {
+            for (uint64_t w = lane; w < a.bm_words; w += 64) bm[w] = 0u;
+        } else {
+            for (uint32_t j = lane; j < log_count; j += 64) bm[logi[j] >> 5] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace cph

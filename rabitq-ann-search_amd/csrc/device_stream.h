@@ -1,0 +1,142 @@
+// device_stream.h — streaming FastScan (no graph): the kernel the HBM roofline is quoted on,
+// plus the single-block hook used by the parity tests.
+//
+// One wave = one 32-neighbour block per iteration, grid-stride over the block array; both
+// N-bit stages are evaluated for every block (as search/rabitq_search.hpp:170-200 does when
+// no batch is skipped), reading the block exactly once.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cph_core.h"
+#include "device_fastscan.h"
+
+namespace cph {
+
+struct StreamArgs {
+    const uint8_t* blocks;
+    uint64_t n_blocks;
+    DevLayout L;
+    const uint4* qmask;   // [PW]
+    QP qp;
+    float dqp;
+    float* sink;          // one float per wave (checksum, defeats DCE)
+    float* out_est;       // optional [count][32] for blocks [first, first+count)
+    float* out_lower;
+    uint64_t first, count;
+};
+
+template <int BW, int SD>
+__global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* qm = reinterpret_cast<uint4*>(smem);
+    const uint32_t PW = SD ? (SD >= 32 ? SD / 32 : 1) : a.L.PW;
+    for (uint32_t w = threadIdx.x; w < PW; w += blockDim.x) qm[w] = a.qmask[w];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const float sq = __fsqrt_rn(a.dqp);
+    float acc = 0.0f;
+    const uint64_t lo = a.out_est ? a.first : 0;
+    const uint64_t hi = a.out_est ? a.first + a.count : a.n_blocks;
+    for (uint64_t b = lo + wave; b < hi; b += nwaves) {
+        const uint8_t* blk = a.blocks + b * a.L.stride;
+        LaneEst v;
+        load_block<BW, SD>(blk, a.L, qm, lane, v);
+        float est, lower;
+        if constexpr (BW == 1) {
+            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+            acc += est + lower;
+        } else {
+            float lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+            acc += est + lower + lo1;
+        }
+        if (a.out_est && lane < 32) {
+            a.out_est[(b - a.first) * 32 + lane] = est;
+            a.out_lower[(b - a.first) * 32 + lane] = lower;
+        }
+    }
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0 && !a.out_est) a.sink[wave] = acc;
+}
+
+// Parity hook: one block of a loaded index, all intermediate values.
+struct BlockHookArgs {
+    const uint8_t* blk;
+    DevLayout L;
+    const uint4* qmask;
+    QP qp;
+    float dqp, worst;
+    int nn_full;
+    uint32_t* sums;   // [32]
+    uint32_t* msb;    // [32]
+    float* est;       // [32]
+    float* lower;     // [32]
+    float* lower1;    // [32]
+};
+
+template <int BW, int SD>
+__global__ __launch_bounds__(64) void block_hook_kernel(BlockHookArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* qm = reinterpret_cast<uint4*>(smem);
+    const uint32_t PW = SD ? (SD >= 32 ? SD / 32 : 1) : a.L.PW;
+    const int lane = threadIdx.x;
+    for (uint32_t w = lane; w < PW; w += 64) qm[w] = a.qmask[w];
+    __syncthreads();
+    LaneEst v;
+    load_block<BW, SD>(a.blk, a.L, qm, lane, v);
+    const uint32_t count = *reinterpret_cast<const uint32_t*>(a.blk + a.L.count_off);
+    const float sq = __fsqrt_rn(a.dqp);
+    float est, lower, lo1;
+    if constexpr (BW == 1) {
+        stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+        lo1 = lower;
+    } else {
+        lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
+        bool surv = (!a.nn_full) || ((lane & 31) < (int)count && lo1 < a.worst);
+        if (__any(surv)) {
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+        } else {
+            est = 3.402823466e+38f;
+            lower = lo1;
+        }
+    }
+    // lanes 32..63 carry the same neighbour as lanes 0..31: let the upper half write so the
+    // redundant-half path is what the test sees for half of the outputs
+    const int i = lane & 31;
+    const bool writer = (i < 16) ? (lane < 32) : (lane >= 32);
+    if (writer) {
+        a.sums[i] = v.nbit;
+        a.msb[i] = v.msb;
+        a.est[i] = est;
+        a.lower[i] = lower;
+        a.lower1[i] = lo1;
+    }
+}
+
+// Exact-L2 hook: one query (padded, device) against ids[0..n).
+__global__ __launch_bounds__(64) void exact_l2_hook_kernel(const float* __restrict__ q,
+                                                           const float* __restrict__ raw,
+                                                           const float* __restrict__ norm_sq,
+                                                           const uint32_t* __restrict__ ids,
+                                                           uint64_t n, uint32_t D, float* out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* qv = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x;
+    for (uint32_t d = lane; d < D; d += 64) qv[d] = q[d];
+    __syncthreads();
+    float c = 0.0f;
+    for (uint32_t i = lane & 7; i < D; i += 8) c = __fmaf_rn(qv[i], qv[i], c);
+    const float qnorm = group_reduce8(c);
+    const int g = lane >> 3;
+    for (uint64_t base = (uint64_t)blockIdx.x * 8; base < n; base += (uint64_t)gridDim.x * 8) {
+        const bool have = base + g < n;
+        const uint32_t id = have ? ids[base + g] : ids[0];
+        float dot = group_dot8(qv, raw + (size_t)id * D, D, lane & 7);
+        float ex = exact_from_dot(qnorm, norm_sq[id], dot);
+        if (have && (lane & 7) == 0) out[base + g] = ex;
+    }
+}
+
+}  // namespace cph

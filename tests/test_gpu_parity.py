@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path (through the C-ABI / Python drop-in) against the reference's golden
+vectors and the oracle.  Bit-exact everywhere: integer sums, fp32 estimates and bounds
+(tolerance stated by north_star is 1e-4 relative — we hold 0 ulp), exact-L2 distances and
+the final ids/distances including duplicates and ties.
+"""
+import numpy as np
+import pytest
+
+from golden_util import DATASETS, KS, fixture_path
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(n, b, v) for n, s in DATASETS.items() for b in s["bits"] for v in s["variants"]]
+
+
+def _beq(a, b):
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.fixture(scope="module")
+def cph():
+    import cphnsw_mi355x
+    return cphnsw_mi355x
+
+
+def _load(cph, name, bits, variant="plain"):
+    ix = cph.CPIndex(DATASETS[name]["dim"], bits)
+    ix.load(fixture_path(name, bits, variant))
+    return ix
+
+
+@pytest.mark.parametrize("name,bits,variant", CASES)
+def test_search_batch_matches_reference(cph, gold, name, bits, variant):
+    ix = _load(cph, name, bits, variant)
+    Q = gold[f"Q/{name}"]
+    for k in KS:
+        ids, d = ix.search_batch(Q, k)
+        assert ids.dtype == np.int64 and d.dtype == np.float32 and ids.shape == (len(Q), k)
+        assert np.array_equal(ids, gold[f"S/{name}/b{bits}/{variant}/k{k}/ids"]), (name, bits, variant, k)
+        assert _beq(d, gold[f"S/{name}/b{bits}/{variant}/k{k}/d"]), (name, bits, variant, k)
+
+
+@pytest.mark.parametrize("name,bits,variant", [c for c in CASES if c[2] in ("plain", "gamma")])
+def test_search_single_unpadded(cph, gold, name, bits, variant):
+    ix = _load(cph, name, bits, variant)
+    Q = gold[f"Q/{name}"]
+    for qi in range(4):
+        ids, d = ix.search(Q[qi], 10)
+        assert np.array_equal(ids, gold[f"S1/{name}/b{bits}/{variant}/q{qi}/ids"])
+        assert _beq(d, gold[f"S1/{name}/b{bits}/{variant}/q{qi}/d"])
+    # float64 queries are force-cast like pybind11's forcecast
+    ids64, _ = ix.search(Q[1].astype(np.float64), 10)
+    assert np.array_equal(ids64, gold[f"S1/{name}/b{bits}/{variant}/q1/ids"])
+
+
+@pytest.mark.parametrize("name,bits", [(n, b) for n, s in DATASETS.items() for b in s["bits"]])
+def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
+    ix = _load(cph, name, bits)
+    oi = oracle.load(fixture_path(name, bits))
+    Q = gold[f"Q/{name}"]
+    rng = np.random.default_rng(5)
+    D = DATASETS[name]["D"]
+    for qi in (0, 3, 7):
+        lut, co = ix.encode_query(Q[qi])
+        olut, oco, _ = oracle.encode_query(Q[qi], D)
+        assert np.array_equal(lut, olut) and _beq(co, oco)
+        assert ix.entry_point(Q[qi]) == oi.entry_point(Q[qi])
+        for qp_tail, dqp in (((1.0, 0.0, 0.0, 0.1), 37.5), ((0.93, 0.02, 0.55, -0.05), 2.5e3),
+                             ((1.0, 0.0, 0.0, 0.0), 0.0), ((1.0, 0.0, 0.0, 0.3), 5e-13)):
+            qp = np.array([co[0], co[1], co[2], *qp_tail], np.float32)
+            for v in rng.integers(0, oi.n, 6):
+                s, m, e, lo, lo1 = ix.fastscan_block(lut, qp, v, dqp)
+                os_, om, oe, olo, olo1 = oi.fastscan_vertex(lut, qp, v, dqp)
+                assert np.array_equal(s, os_) and np.array_equal(m, om), (name, bits, v)
+                assert _beq(e, oe) and _beq(lo, olo) and _beq(lo1, olo1), (name, bits, v, dqp)
+                if bits > 1:
+                    # stage-2 skip: result heap full and a threshold below every stage-1 bound
+                    thr = float(np.min(olo1)) * 0.5
+                    if thr > 0:
+                        _, _, e2, lo2, _ = ix.fastscan_block(lut, qp, v, dqp, worst=thr, nn_full=True)
+                        assert np.all(e2 == np.float32(3.402823466e+38)) and _beq(lo2, olo1)
+                    thr = float(np.min(olo1)) * 1.5 + 1e-3
+                    _, _, e3, lo3, _ = ix.fastscan_block(lut, qp, v, dqp, worst=thr, nn_full=True)
+                    assert _beq(e3, oe) and _beq(lo3, olo)
+        ids = rng.integers(0, oi.n, 50).astype(np.uint32)
+        assert _beq(ix.exact_l2(Q[qi], ids), oi.exact_l2(Q[qi], ids))
+
+
+@pytest.mark.parametrize("D,bits", [(16, 1), (16, 4), (64, 2), (128, 1), (128, 2), (128, 4),
+                                    (256, 1), (512, 2), (1024, 4), (2048, 1), (2048, 4)])
+def test_stream_blocks_match_oracle(cph, oracle, D, bits):
+    st = cph.FastScanStream(D, bits, 300, seed=9)
+    L = oracle.layout(D, bits)
+    nb_bytes = L[0] - L[1]
+    blocks, lut, qp, dqp = st.export(0, 300, nb_bytes)
+    est, lower = st.eval(0, 300)
+    blocks = blocks.reshape(300, nb_bytes)
+    for b in (0, 1, 17, 299):
+        nb = blocks[b]
+        planes = nb[L[2]:L[2] + bits * D * 4].reshape(bits, D // 8, 32)
+        nop = nb[L[3]:L[3] + 128].view(np.float32)
+        ipqo = nb[L[4]:L[4] + 128].view(np.float32)
+        ipcp = nb[L[5]:L[5] + 128].view(np.float32)
+        pop = nb[L[6]:L[6] + 64].view(np.uint16)
+        if bits == 1:
+            s = oracle.fastscan_plane(D, lut, planes[0])
+            e, lo = oracle.convert_1bit(D, qp, s, nop, ipqo, ipcp, pop, dqp)
+        else:
+            wpop = nb[L[7]:L[7] + 64].view(np.uint16)
+            s, m = oracle.fastscan_nbit(D, bits, lut, planes)
+            e, lo = oracle.convert_nbit(D, bits, qp, s, m, nop, ipqo, ipcp, pop, wpop, dqp)
+        assert _beq(est[b], e) and _beq(lower[b], lo), (D, bits, b)
+    ms, ck = st.run(2)
+    assert ms > 0 and np.isfinite(ck)
+    st.close()
+
+
+def test_save_roundtrip_is_byte_identical(cph, tmp_path):
+    ix = _load(cph, "g128", 4)
+    p = tmp_path / "out.idx"
+    ix.save(str(p))
+    assert p.read_bytes() == open(fixture_path("g128", 4), "rb").read()
+    assert ix.size == DATASETS["g128"]["n"] and ix.dim == 128 and ix.is_finalized
+
+
+def test_api_errors(cph, tmp_path):
+    with pytest.raises(ValueError, match="Unsupported bits=3"):
+        cph.CPIndex(128, 3)
+    with pytest.raises(ValueError, match="Unsupported dimension 4096"):
+        cph.CPIndex(4096, 1)
+    ix = cph.CPIndex(128, 4)
+    assert not ix.is_finalized and ix.size == 0
+    with pytest.raises(RuntimeError, match="must be finalized"):
+        ix.save(str(tmp_path / "x.idx"))
+    with pytest.raises(RuntimeError):
+        ix.search(np.zeros(128, np.float32), 10)
+    with pytest.raises(ValueError, match="query must be 1D"):
+        ix.search(np.zeros((2, 128), np.float32), 10)
+    with pytest.raises(ValueError, match="queries must be"):
+        ix.search_batch(np.zeros((2, 64), np.float32), 10)
+    bad = tmp_path / "bad.idx"
+    bad.write_bytes(b"\0" * 200)
+    with pytest.raises(RuntimeError, match="Invalid magic"):
+        ix.load(str(bad))
+    with pytest.raises(RuntimeError, match="template parameters mismatch"):
+        ix.load(fixture_path("g128", 2))
+    trunc = tmp_path / "trunc.idx"
+    trunc.write_bytes(open(fixture_path("g128", 4), "rb").read()[:100000])
+    with pytest.raises(RuntimeError, match="truncated"):
+        ix.load(str(trunc))
+    assert not ix.is_finalized  # failed loads leave the index untouched
+    ix.load(fixture_path("g128", 4))
+    ids, d = ix.search_batch(np.zeros((0, 128), np.float32), 10)
+    assert ids.shape == (0, 10)
+    ids, d = ix.search(np.ones(128, np.float32), 0)   # k clamped to >= 1
+    assert len(ids) == 1
+
+
+def test_capacity_overflow_rerun_is_exact(cph, gold):
+    """A tiny per-slot capacity forces the overflow -> full-capacity re-run path."""
+    ix = _load(cph, "g128", 2)
+    ix.set_search_params(slots=8, beam_capacity=64)
+    Q = gold["Q/g128"]
+    ids, d = ix.search_batch(Q, 10)
+    assert ix.last_search_stats()["rerun_queries"] > 0
+    assert np.array_equal(ids, gold["S/g128/b2/plain/k10/ids"]) and _beq(d, gold["S/g128/b2/plain/k10/d"])
+
+
+def test_large_index_against_oracle(cph, oracle, tmp_path):
+    """Bigger graph (many thousands of expansions per query): GPU vs the oracle on an index built
+    by the compiled reference when it is available on this box."""
+    from oracle_lib import ref_available, ref_module
+    if not ref_available():
+        pytest.skip("oracle/_ref not present on this box")
+    m = ref_module()
+    rng = np.random.default_rng(77)
+    n, dim = 20000, 128
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((64, dim)).astype(np.float32)
+    for bits in (1, 4):
+        ridx = m.CPIndex(dim, bits)
+        ridx.build(X)
+        ridx.finalize()
+        p = str(tmp_path / f"big_{bits}.idx")
+        ridx.save(p)
+        ix = cph.CPIndex(dim, bits)
+        ix.load(p)
+        for k in (10, 100):
+            rids, rd = ridx.search_batch(Q, k)
+            ids, d = ix.search_batch(Q, k)
+            assert np.array_equal(ids, rids), (bits, k)
+            assert _beq(d, rd), (bits, k)
