@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native CP-HNSW hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): SIFT1M-class synthetic data, dim 128 (D=128), 4-bit RaBitQ
+codes, R=32, k=10.  A step = one `search_batch` pass of the layer-0 hot path over the rank's
+shard of a fixed query batch, queries resident in HBM, plus the RCCL all-gather of the
+results.  Queries shard across ranks; the index is replicated (weak scaling: nq per GPU fixed).
+
+The JSON line also carries
+  * fastscan_stream: the streaming FastScan kernel on 1M synthetic D=128/4-bit neighbour blocks
+    (metric part 2: distances/s vs the HBM roofline),
+  * roofline: the dominant kernel of the timed region (the persistent search kernel),
+    algorithmic bytes = expansions x (32 x 84 B) + exact-L2 evaluations x 516 B, measured with HIP
+    events on the launch stream inside the library,
+  * cpu_baseline: the reference (oracle/_ref) or the scalar port (oracle/) on this box' host
+    cores, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
+DIM, BITS, K = 128, 4, 10
+BYTES_PER_DIST = DIM * BITS // 8 + 20      # 84 B
+BYTES_PER_EXACT = 4 * DIM + 4              # 516 B
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def sift_like(rng, n, dim, ncl, centers=None):
+    """SURVEY.md §8(d) C2 generator: clustered, integer-valued, clipped to [0, 218]."""
+    if centers is None:
+        centers = rng.gamma(2.0, 15.0, (ncl, dim))
+    X = centers[rng.integers(0, len(centers), n)] + rng.normal(0.0, 12.0, (n, dim))
+    return np.clip(np.round(X), 0, 218).astype(np.float32), centers
+
+
+def make_data(n, nq, seed=1):
+    rng = np.random.default_rng(seed)
+    ncl = max(10, n // 1000)
+    X, c = sift_like(rng, n, DIM, ncl)
+    Q, _ = sift_like(rng, nq, DIM, ncl, c)
+    return X, Q
+
+
+def get_index_file(args, rank, X):
+    """Index for the end-to-end leg.  Until the host-side builder lands the
+    index is produced by the compiled reference as part of the cpu_baseline leg (it has to
+    build it anyway to be timed on it) and handed to the GPU path as a v2 file."""
+    path = os.path.join(args.workdir, f"bench_n{args.n_index}_b{BITS}.idx")
+    info = {"builder": None, "build_s": None}
+    if rank == 0 and not os.path.exists(path):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import ref_available, ref_module
+        if not ref_available():
+            raise RuntimeError("no index builder available on this box (oracle/_ref missing)")
+        t0 = time.time()
+        idx = ref_module().CPIndex(DIM, BITS)
+        idx.build(X)
+        idx.finalize()
+        idx.save(path + ".tmp")
+        os.replace(path + ".tmp", path)
+        info = {"builder": "reference (cpu_baseline leg)", "build_s": round(time.time() - t0, 1)}
+        log(f"[bench] reference built n={args.n_index} in {info['build_s']} s")
+    return path, info
+
+
+def cpu_baseline(args, path, Q, stream):
+    """Reference (or port) on the host cores: bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle, RefHooks, ref_available, ref_module
+    cores = os.cpu_count() or 1
+    out = {"cores": cores}
+    sample_q = Q[: min(len(Q), args.cpu_queries)]
+    if ref_available():
+        idx = ref_module().CPIndex(DIM, BITS)
+        idx.load(path)
+        idx.search_batch(sample_q[:64], K)
+        t0 = time.time()
+        idx.search_batch(sample_q, K)
+        dt = time.time() - t0
+        out.update(kind="reference", value=len(sample_q) / dt, unit="qps")
+        # streaming FastScan, same blocks and query as the GPU stream leg
+        L = Oracle().layout(DIM, BITS)
+        nb = min(stream.n_blocks, 200_000)
+        blocks, lut, qp, dqp = stream.export(0, nb, L[0] - L[1])
+        import ctypes as C
+        r = RefHooks()
+        f = r.lib.ref_fastscan_stream
+        ck = C.c_double()
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_int,
+                      C.POINTER(C.c_double)]
+        f(DIM, BITS, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, 1, C.byref(ck))
+        reps = 8
+        t0 = time.time()
+        f(DIM, BITS, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, reps, C.byref(ck))
+        dt2 = time.time() - t0
+        out["fastscan_dist_per_s"] = nb * 32 * reps / dt2
+        out["sample"] = (f"{len(sample_q)} queries of the same batch on the same index, k={K}, "
+                         f"search_batch with {cores} OpenMP threads; FastScan: {nb} of the same blocks x {reps}")
+    else:
+        oi = Oracle().load(path)
+        sample_q = sample_q[: max(64, args.cpu_queries // 8)]
+        t0 = time.time()
+        oi.search_batch(sample_q, K, nthreads=cores)
+        dt = time.time() - t0
+        out.update(kind="port", value=len(sample_q) / dt, unit="qps",
+                   sample=f"{len(sample_q)} queries, scalar oracle port, {cores} threads")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 100_000)))
+    ap.add_argument("--nq-per-gpu", type=int, default=10_000)
+    ap.add_argument("--stream-blocks", type=int, default=1_000_000)
+    ap.add_argument("--cpu-queries", type=int, default=2_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    os.makedirs(args.workdir, exist_ok=True)
+
+    import cphnsw_mi355x
+    from cphnsw_mi355x.dist import gather_results
+
+    # ---- data, index ----------------------------------------------------------------------
+    nq_total = args.nq_per_gpu * world
+    X, Q = make_data(args.n_index, nq_total)
+    path, build_info = get_index_file(args, rank, X)
+    if world > 1:
+        dist.barrier()
+    index = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
+    t0 = time.time()
+    index.load(path)
+    load_s = time.time() - t0
+    q_shard = torch.from_numpy(Q[rank * args.nq_per_gpu:(rank + 1) * args.nq_per_gpu]).to(dev)
+
+    def step():
+        ids, d = index.search_batch_device(q_shard, K)
+        return gather_results(ids, d, world)
+
+    # ---- end-to-end search ----------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    kernel_us = []
+    stats = None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, d = step()
+        stats = index.last_search_stats()
+        kernel_us.append(stats["kernel_us"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    qps = nq_total * args.steps / elapsed
+
+    # roofline of the dominant kernel (persistent search kernel), rank 0's launches
+    k_s = float(np.mean(kernel_us)) * 1e-6
+    alg_bytes = stats["expansions"] * 32 * BYTES_PER_DIST + stats["exact_l2"] * BYTES_PER_EXACT
+    achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
+
+    # ---- FastScan stream (metric part 2) -----------------------------------------------------
+    stream = cphnsw_mi355x.FastScanStream(DIM, BITS, args.stream_blocks, seed=4, device=local)
+    stream.run(2)
+    ms, _ = stream.run(10)
+    fs_dist_s = args.stream_blocks * 32 / (ms * 1e-3)
+    fs_gbs = fs_dist_s * BYTES_PER_DIST / 1e9
+
+    out = None
+    if rank == 0:
+        ids_np = ids.cpu().numpy()
+        out = {
+            "metric": "qps (search_batch, k=10) + fastscan_dist_per_s",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 popcount / f32",
+            "data": "synthetic",
+            "config": {"workload": f"SIFT-like synthetic {args.n_index}x{DIM} f32 (int-valued, clustered), "
+                                   f"{BITS}-bit RaBitQ FastScan + exact-L2 rerank, R=32, k={K}",
+                       "n_index": args.n_index, "dim": DIM, "bits": BITS, "k": K,
+                       "nq_per_gpu": args.nq_per_gpu, "index_builder": build_info["builder"],
+                       "parallelism": f"query-sharded x{world}, index replicated"},
+            "fastscan_stream": {"dist_per_s": fs_dist_s, "blocks": args.stream_blocks,
+                                "ms_per_pass": ms, "bytes_per_dist": BYTES_PER_DIST,
+                                "roofline": {"bound": "hbm", "achieved": fs_gbs, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": fs_gbs / HBM_PEAK_GBS,
+                                             "traffic": None}},
+            "roofline": {"bound": "hbm", "kernel": "search_kernel<4,128>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_s * 1e3,
+                         "expansions_per_query": stats["expansions"] / args.nq_per_gpu,
+                         "exact_l2_per_query": stats["exact_l2"] / args.nq_per_gpu},
+            "search_stats": stats,
+            "index_load_s": load_s,
+            "dup_slots_per_query": float((ids_np[:, 1:] == ids_np[:, :-1]).sum(1).mean()),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

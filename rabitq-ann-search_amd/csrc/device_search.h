@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 ++slack_batch;
             }
             const float dqp = exact_dist;
-            const float sq = __fsqrt_rn(dqp);
+            const float sq = __builtin_sqrtf(dqp);
 
             // ---- FastScan estimates (:159-206) ----------------------------------------
             float est, lower;

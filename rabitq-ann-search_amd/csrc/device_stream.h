@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const float sq = __fsqrt_rn(a.dqp);
+    const float sq = __builtin_sqrtf(a.dqp);
     float acc = 0.0f;
     const uint64_t lo = a.out_est ? a.first : 0;
     const uint64_t hi = a.out_est ? a.first + a.count : a.n_blocks;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void block_hook_kernel(BlockHookArgs a) {
     LaneEst v;
     load_block<BW, SD>(a.blk, a.L, qm, lane, v);
     const uint32_t count = *reinterpret_cast<const uint32_t*>(a.blk + a.L.count_off);
-    const float sq = __fsqrt_rn(a.dqp);
+    const float sq = __builtin_sqrtf(a.dqp);
     float est, lower, lo1;
     if constexpr (BW == 1) {
         stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);

@@ -82,6 +82,13 @@ def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
                     thr = float(np.min(olo1)) * 1.5 + 1e-3
                     _, _, e3, lo3, _ = ix.fastscan_block(lut, qp, v, dqp, worst=thr, nn_full=True)
                     assert _beq(e3, oe) and _beq(lo3, olo)
+        # many random parent distances: sqrt and the divisions must be correctly rounded
+        qp = np.array([co[0], co[1], co[2], 0.97, 0.01, 0.2, 0.07], np.float32)
+        for dqp in rng.uniform(0.01, 3e4, 40).astype(np.float32):
+            v = int(rng.integers(0, oi.n))
+            s, m, e, lo, lo1 = ix.fastscan_block(lut, qp, v, float(dqp))
+            os_, om, oe, olo, olo1 = oi.fastscan_vertex(lut, qp, v, float(dqp))
+            assert _beq(e, oe) and _beq(lo, olo) and _beq(lo1, olo1), (name, bits, v, dqp)
         ids = rng.integers(0, oi.n, 50).astype(np.uint32)
         assert _beq(ix.exact_l2(Q[qi], ids), oi.exact_l2(Q[qi], ids))
 
