@@ -18,6 +18,7 @@
 
 #include "../../include/cphnsw_mi355x.h"
 #include "cph_core.h"
+#include "device_encode.h"
 #include "device_fastscan.h"
 #include "device_search.h"
 #include "device_stream.h"
@@ -140,7 +141,14 @@ struct cph_index {
     // device-resident index
     DevBuf<uint8_t> d_blocks;
     DevBuf<float> d_raw, d_norm;
+    // per-query feeders on the device: rotation signs + upper layers (CSR)
+    DevBuf<float> d_signs;
+    DevBuf<uint32_t> d_upper;          // all layers' nodes | offsets | nbrs, concatenated
+    UpperLayerDev layers[kMaxUpperLayers];
+    int32_t dev_max_level = 0;
+    float norm_factor = 0.0f, inv_sqrt_d = 0.0f;
     // per-batch query staging + outputs
+    DevBuf<float> d_queries_raw;
     DevBuf<float> d_queries;
     DevBuf<uint4> d_qmasks;
     DevBuf<QueryHeader> d_qhdr;
@@ -198,6 +206,35 @@ void upload_index(cph_index* h) {
     }
     HIP_CHECK(hipMemcpy(h->d_raw.p, hi.raw.data(), n * hi.D * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(h->d_norm.p, hi.norm_sq.data(), n * 4, hipMemcpyHostToDevice));
+    // rotation signs and the scale factors of the query encoder (rabitq_encoder.hpp:37-39)
+    h->d_signs.alloc(3 * hi.D);
+    HIP_CHECK(hipMemcpy(h->d_signs.p, hi.rot.signs.data(), 3 * hi.D * 4, hipMemcpyHostToDevice));
+    const float d = static_cast<float>(hi.D);
+    h->norm_factor = 1.0f / (d * std::sqrt(d));
+    h->inv_sqrt_d = 1.0f / std::sqrt(d);
+    // upper layers as CSR (edges are stored sorted by node id, api/hnsw_index.hpp:152)
+    const int nl = std::min<int>({(int)hi.upper.size(), (int)hi.max_level, kMaxUpperLayers});
+    h->dev_max_level = hi.max_level > 0 ? nl : 0;
+    std::vector<uint32_t> flat;
+    std::vector<size_t> off_nodes(nl), off_offs(nl), off_nbrs(nl);
+    for (int l = 0; l < nl; ++l) {
+        const auto& layer = hi.upper[l];
+        off_nodes[l] = flat.size();
+        for (const auto& e : layer) flat.push_back(e.node);
+        off_offs[l] = flat.size();
+        uint32_t acc = 0;
+        for (const auto& e : layer) { flat.push_back(acc); acc += (uint32_t)e.nbrs.size(); }
+        flat.push_back(acc);
+        off_nbrs[l] = flat.size();
+        for (const auto& e : layer) flat.insert(flat.end(), e.nbrs.begin(), e.nbrs.end());
+    }
+    h->d_upper.alloc(flat.size() + 1);
+    if (!flat.empty())
+        HIP_CHECK(hipMemcpy(h->d_upper.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    for (int l = 0; l < kMaxUpperLayers; ++l) h->layers[l] = UpperLayerDev{nullptr, nullptr, nullptr, 0};
+    for (int l = 0; l < nl; ++l)
+        h->layers[l] = UpperLayerDev{h->d_upper.p + off_nodes[l], h->d_upper.p + off_offs[l],
+                                     h->d_upper.p + off_nbrs[l], (uint32_t)hi.upper[l].size()};
     h->scratch_slots = 0;
     h->scratch_cap = 0;
 }
@@ -214,37 +251,43 @@ void ensure_scratch(cph_index* h, uint32_t slots, uint64_t cap) {
     h->scratch_cap = cap;
 }
 
-// Encode queries on the host (rotation, LUT scalars, upper-layer descent) and stage them.
-void stage_queries(cph_index* h, const float* queries, uint64_t nq, hipStream_t st) {
+// Encode the queries on the device (rotation, 4-bit scalars -> masks, coefficients) and run the
+// upper-layer descent; d_raw_q = [nq][dim] raw queries already in HBM.
+void stage_queries(cph_index* h, const float* d_raw_q, uint64_t nq, hipStream_t st) {
     const HostIndex& hi = h->host;
-    const size_t D = hi.D, PW = h->L.PW, dim = hi.dim;
-    std::vector<float> padded(nq * D, 0.0f);
-    std::vector<uint32_t> masks(nq * PW * 4);
-    std::vector<QueryHeader> hdr(nq);
-    std::atomic<bool> bad{false};
-    parallel_for(nq, 16, [&](size_t lo, size_t hi_) {
-        std::vector<float> buf(D);
-        EncodedQuery eq;
-        for (size_t i = lo; i < hi_; ++i) {
-            float* p = &padded[i * D];
-            std::memcpy(p, queries + i * dim, dim * sizeof(float));
-            std::memcpy(buf.data(), p, D * sizeof(float));
-            encode_query(hi.rot, buf.data(), eq);
-            qu_to_masks(eq.qu.data(), D, &masks[i * PW * 4]);
-            hdr[i].A = eq.A; hdr[i].B = eq.B; hdr[i].C = eq.C;
-            uint32_t ep = hi.entry_point(p);
-            if (ep == kInvalidNode || ep >= hi.n) bad = true;
-            hdr[i].entry = ep;
-        }
-    });
-    if (bad) throw std::runtime_error("Search failed: invalid entry point after finalize.");
+    const uint32_t D = (uint32_t)hi.D, PW = h->L.PW;
     h->d_queries.alloc(nq * D);
     h->d_qmasks.alloc(nq * PW);
     h->d_qhdr.alloc(nq);
-    HIP_CHECK(hipMemcpyAsync(h->d_queries.p, padded.data(), nq * D * 4, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(h->d_qmasks.p, masks.data(), nq * PW * 16, hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(h->d_qhdr.p, hdr.data(), nq * sizeof(QueryHeader), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));  // host vectors go out of scope
+    EncodeArgs a{};
+    a.queries_raw = d_raw_q;
+    a.nq = (uint32_t)nq;
+    a.dim = (uint32_t)hi.dim;
+    a.D = D;
+    a.PW = PW;
+    a.signs = h->d_signs.p;
+    a.norm_factor = h->norm_factor;
+    a.inv_sqrt_d = h->inv_sqrt_d;
+    a.raw = h->d_raw.p;
+    a.n = hi.n;
+    a.entry = hi.entry;
+    a.max_level = h->dev_max_level;
+    for (int l = 0; l < kMaxUpperLayers; ++l) a.layers[l] = h->layers[l];
+    a.queries_padded = h->d_queries.p;
+    a.qmasks = h->d_qmasks.p;
+    a.qhdr = h->d_qhdr.p;
+    if (hi.entry == kInvalidNode || hi.entry >= hi.n)
+        throw std::runtime_error("Search failed: invalid entry point after finalize.");
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)h->num_cus * 32);
+    hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), encode_lds_bytes(D), st, a);
+    HIP_CHECK(hipGetLastError());
+}
+
+// host queries -> device staging buffer
+const float* upload_queries(cph_index* h, const float* queries, uint64_t nq, hipStream_t st) {
+    h->d_queries_raw.alloc(nq * h->dim);
+    HIP_CHECK(hipMemcpyAsync(h->d_queries_raw.p, queries, nq * h->dim * 4, hipMemcpyHostToDevice, st));
+    return h->d_queries_raw.p;
 }
 
 void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
@@ -472,7 +515,7 @@ int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k,
         if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
         h->use_device();
         hipStream_t st = nullptr;
-        stage_queries(h, queries, n, st);
+        stage_queries(h, upload_queries(h, queries, n, st), n, st);
         h->d_ids.alloc(n * k);
         h->d_dist.alloc(n * k);
         run_search(h, (uint32_t)n, (uint32_t)k, h->d_ids.p, h->d_dist.p, st);
@@ -491,12 +534,7 @@ int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, ui
         if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
         h->use_device();
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        // the query encoder and the upper-layer descent still run on the host this round
-        // (SURVEY.md §8f N3 moves them on-device): round-trip the raw queries
-        std::vector<float> hq(n * h->dim);
-        HIP_CHECK(hipMemcpyAsync(hq.data(), d_queries, n * h->dim * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        stage_queries(h, hq.data(), n, st);
+        stage_queries(h, d_queries, n, st);
         run_search(h, (uint32_t)n, (uint32_t)k, d_ids, d_dist, st);
     });
 }
@@ -511,7 +549,7 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
         if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
         h->use_device();
         hipStream_t st = nullptr;
-        stage_queries(h, query, 1, st);
+        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
         h->d_ids.alloc(kk);
         h->d_dist.alloc(kk);
         run_search(h, 1, (uint32_t)kk, h->d_ids.p, h->d_dist.p, st);
@@ -529,15 +567,23 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
 int cph_encode_query(cph_index* h, const float* query, uint8_t* lut, float* coeffs) {
     return guarded([&] {
         std::lock_guard<std::mutex> lk(h->mu);
-        Rotation local;
-        const Rotation* rot = &h->host.rot;
-        if (rot->D != h->D) { local.init(h->D, 42); rot = &local; }
-        std::vector<float> buf(h->D, 0.0f);
-        std::memcpy(buf.data(), query, h->dim * sizeof(float));
-        EncodedQuery eq;
-        encode_query(*rot, buf.data(), eq);
-        qu_to_lut(eq.qu.data(), h->D, lut);
-        coeffs[0] = eq.A; coeffs[1] = eq.B; coeffs[2] = eq.C;
+        require_finalized(h);  // the device encoder lives with the loaded index
+        h->use_device();
+        hipStream_t st = nullptr;
+        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
+        const uint32_t D = h->D, PW = h->L.PW;
+        std::vector<uint32_t> masks(PW * 4);
+        QueryHeader hd;
+        HIP_CHECK(hipMemcpy(masks.data(), h->d_qmasks.p, PW * 16, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&hd, h->d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> qu(D);
+        for (uint32_t d = 0; d < D; ++d) {
+            uint8_t u = 0;
+            for (int j = 0; j < 4; ++j) u |= (uint8_t)(((masks[(d / 32) * 4 + j] >> (d % 32)) & 1u) << j);
+            qu[d] = u;
+        }
+        qu_to_lut(qu.data(), D, lut);
+        coeffs[0] = hd.A; coeffs[1] = hd.B; coeffs[2] = hd.C;
     });
 }
 
@@ -545,9 +591,12 @@ int cph_entry_point(cph_index* h, const float* query, uint32_t* entry) {
     return guarded([&] {
         std::lock_guard<std::mutex> lk(h->mu);
         require_finalized(h);
-        std::vector<float> buf(h->D, 0.0f);
-        std::memcpy(buf.data(), query, h->dim * sizeof(float));
-        *entry = h->host.entry_point(buf.data());
+        h->use_device();
+        hipStream_t st = nullptr;
+        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
+        QueryHeader hd;
+        HIP_CHECK(hipMemcpy(&hd, h->d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+        *entry = hd.entry;
     });
 }
 

@@ -1,13 +1,13 @@
 // host_index.h — host side of the hot path: v2 index file reader/writer, the repacker that
-// turns reference-layout neighbour blocks into the device layout, and the per-query
-// feeders that stay on the host in this round (query encoder, upper-layer descent).
+// turns reference-layout neighbour blocks into the device layout, and the host mirror of the
+// query encoder (used to make the synthetic query of the streaming benchmark; queries of a
+// search are encoded on the device, device_encode.h).
 //
 // Reference counterparts (relative to /root/reference/include/cphnsw/):
 //   api/hnsw_index.hpp:217-303 save, :305-443 load            -> HostIndex::save / load
 //   graph/rabitq_graph.hpp:19-29, distance/fastscan_layout.hpp -> repack_* (layout only)
 //   encoder/rotation.hpp:15-67, encoder/transform/fht.hpp:23-57 -> Rotation
 //   encoder/rabitq_encoder.hpp:73-79,98-136,197-209            -> encode_query
-//   api/hnsw_index.hpp:196-202,468-474,617-638                 -> entry_point
 // This file is compiled with -ffp-contract=off; each fused multiply-add is explicit and
 // sits where the compiled reference has one.
 #pragma once
@@ -117,21 +117,6 @@ inline void qu_to_lut(const uint8_t* qu, size_t D, uint8_t* lut) {
 }
 inline void lut_to_qu(const uint8_t* lut, size_t D, uint8_t* qu) {
     for (size_t d = 0; d < D; ++d) qu[d] = lut[(d / 4) * 16 + (1u << (d % 4))];
-}
-
-// exact arithmetic with the reference's summation order (core/memory.hpp:65-95)
-inline float reduce8(const float* c) {
-    float s0 = c[0] + c[4], s1 = c[1] + c[5], s2 = c[2] + c[6], s3 = c[3] + c[7];
-    return (s0 + s1) + (s2 + s3);
-}
-inline float l2sq8(size_t D, const float* a, const float* b) {
-    float c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < D; i += 8)
-        for (int j = 0; j < 8; ++j) {
-            float d = a[i + j] - b[i + j];
-            c[j] = std::fmaf(d, d, c[j]);
-        }
-    return reduce8(c);
 }
 
 struct HostIndex {
@@ -301,34 +286,6 @@ struct HostIndex {
 
     const uint8_t* nb(size_t v) const { return &search_data[v * RL.vertex_bytes + RL.nb_off]; }
     const float* vec(size_t v) const { return &raw[v * D]; }
-
-    // api/hnsw_index.hpp:617-638 with find_edge :468-474
-    uint32_t greedy_layer(const float* q, uint32_t ep, int level) const {
-        float best = l2sq8(D, q, vec(ep));
-        uint32_t best_id = ep;
-        const auto& layer = upper[level - 1];
-        bool improved = true;
-        while (improved) {
-            improved = false;
-            auto it = std::lower_bound(layer.begin(), layer.end(), best_id,
-                                       [](const UpperEdge& e, uint32_t v) { return e.node < v; });
-            if (it == layer.end() || it->node != best_id) break;
-            for (uint32_t x : it->nbrs) {
-                float d = l2sq8(D, q, vec(x));
-                if (d < best) { best = d; best_id = x; improved = true; }
-            }
-        }
-        return best_id;
-    }
-    // api/hnsw_index.hpp:196-202
-    uint32_t entry_point(const float* q_padded) const {
-        uint32_t ep = entry;
-        if (max_level > 0 && ep != kInvalidNode && ep < n) {
-            const int top = std::min<int>(max_level, (int)upper.size());
-            for (int level = top; level >= 1; --level) ep = greedy_layer(q_padded, ep, level);
-        }
-        return ep;
-    }
 };
 
 // ---- reference neighbour block <-> device block -----------------------------------------

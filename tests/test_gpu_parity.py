@@ -122,6 +122,18 @@ def test_stream_blocks_match_oracle(cph, oracle, D, bits):
     st.close()
 
 
+@pytest.mark.parametrize("name,bits,D,dim", [("g128", 1, 128, 128), ("sift96", 4, 128, 96),
+                                             ("g16", 2, 16, 10), ("g1024", 2, 1024, 960)])
+def test_device_query_encoder_matches_reference(cph, gold, name, bits, D, dim):
+    """The on-device rotation + LUT scalars + coefficients against the reference's vectors."""
+    ix = _load(cph, name, bits)
+    q = gold[f"E/{D}/{dim}/q"]
+    for i in range(len(q)):
+        lut, co = ix.encode_query(q[i])
+        assert np.array_equal(lut, gold[f"E/{D}/{dim}/lut"][i]), (name, i)
+        assert _beq(co, gold[f"E/{D}/{dim}/coeffs"][i]), (name, i, co, gold[f"E/{D}/{dim}/coeffs"][i])
+
+
 def test_save_roundtrip_is_byte_identical(cph, tmp_path):
     ix = _load(cph, "g128", 4)
     p = tmp_path / "out.idx"
