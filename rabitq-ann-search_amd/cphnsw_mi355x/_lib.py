@@ -48,9 +48,11 @@ def lib():
     be built or loaded the product path is unavailable and this raises."""
     global _LIB
     if _LIB is None:
-        path = _build.LIB_PATH
-        if _build.needs_build():
-            path = _build.build_library()
+        path = os.environ.get("CPH_LIB_PATH")  # diagnostic builds (e.g. -DCPH_PHASE_TIMERS)
+        if not path:
+            path = _build.LIB_PATH
+            if _build.needs_build():
+                path = _build.build_library()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -138,6 +138,7 @@ struct cph_index {
     SearchConsts sc{};
     uint32_t flags = 0;
     int num_cus = 256;
+    uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident query slots per CU (launch bounds of search_kernel)
     // device-resident index
     DevBuf<uint8_t> d_blocks;
     DevBuf<float> d_raw, d_norm;
@@ -159,8 +160,7 @@ struct cph_index {
     DevBuf<unsigned long long> d_stats;
     // per-slot scratch
     DevBuf<uint32_t> d_bitmaps, d_logids;
-    DevBuf<uint2> d_heaps;
-    DevBuf<float> d_lowers;
+    DevBuf<uint4> d_beam;
     uint32_t scratch_slots = 0;
     uint64_t scratch_cap = 0;
     // knobs
@@ -245,8 +245,7 @@ void ensure_scratch(cph_index* h, uint32_t slots, uint64_t cap) {
     h->d_bitmaps.alloc((size_t)slots * bm_words);
     HIP_CHECK(hipMemset(h->d_bitmaps.p, 0, (size_t)slots * bm_words * 4));
     h->d_logids.alloc((size_t)slots * cap);
-    h->d_heaps.alloc((size_t)slots * cap);
-    h->d_lowers.alloc((size_t)slots * cap);
+    h->d_beam.alloc((size_t)slots * cap);
     h->scratch_slots = slots;
     h->scratch_cap = cap;
 }
@@ -310,9 +309,8 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.cap = cap;
     a.bm_words = (h->host.n + 31) / 32;
     a.bitmaps = h->d_bitmaps.p;
-    a.heaps = h->d_heaps.p;
+    a.beam = h->d_beam.p;
     a.log_ids = h->d_logids.p;
-    a.lowers = h->d_lowers.p;
     a.out_ids = d_ids;
     a.out_dist = d_dist;
     a.out_count = h->d_count.p;
@@ -331,11 +329,14 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     h->d_count.alloc(nq);
     h->d_status.alloc(nq);
     h->d_counter.alloc(1);
-    h->d_stats.alloc(8);
-    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 64, st));
+    h->d_stats.alloc(16);
+    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 128, st));
     // resident query slots: one wave each
-    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * 16;
-    uint32_t slots = std::min<uint32_t>(nq, max_slots);
+    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * h->waves_per_cu;
+    // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
+    // would leave 56% of the slots idle during the third round)
+    const uint32_t rounds = (nq + max_slots - 1) / max_slots;
+    uint32_t slots = std::min<uint32_t>(nq, (nq + rounds - 1) / rounds);
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
@@ -345,8 +346,8 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         // budget: at most 60% of what is free (plus what we already hold)
         const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        while (slots > 64 && (uint64_t)slots * (cap * 16 + bm_bytes) > budget) slots /= 2;
-        while (cap > 4096 && (uint64_t)slots * (cap * 16 + bm_bytes) > budget) cap /= 2;
+        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots /= 2;
+        while (cap > 4096 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) cap /= 2;
         ensure_scratch(h, slots, cap);
     } else {
         slots = std::min(slots, h->scratch_slots);
@@ -369,10 +370,10 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         const uint64_t full = n + 1;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
-        uint64_t per = full * 16 + bm_bytes;
+        uint64_t per = full * 20 + bm_bytes;
         uint32_t s2 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>(todo.size(), (uint64_t)((free_b + held) * 0.6) / per));
-        h->d_bitmaps.release(); h->d_logids.release(); h->d_heaps.release(); h->d_lowers.release();
+        h->d_bitmaps.release(); h->d_logids.release(); h->d_beam.release();
         h->scratch_slots = 0; h->scratch_cap = 0;
         ensure_scratch(h, s2, full);
         h->d_todo.alloc(todo.size());
@@ -385,8 +386,12 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         HIP_CHECK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
         ms += ms2;
     }
-    unsigned long long stats[8];
-    HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 64, hipMemcpyDeviceToHost));
+    unsigned long long stats[16];
+    HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 128, hipMemcpyDeviceToHost));
+#ifdef CPH_PHASE_TIMERS
+    fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
+            stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15]);
+#endif
     for (int i = 0; i < 6; ++i) h->last_stats[i] = stats[i];
     h->last_stats[5] = todo.size();
     h->last_stats[6] = (uint64_t)(ms * 1000.0);
@@ -433,6 +438,7 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         h->device = device;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+        if (const char* e = getenv("CPH_WAVES_PER_CU")) h->waves_per_cu = (uint32_t)std::max(1, atoi(e));
         *out = h;
     });
 }
@@ -752,7 +758,8 @@ void stream_launch(cph_stream* s, float* out_est, float* out_lower, uint64_t fir
     a.out_lower = out_lower;
     a.first = first;
     a.count = count;
-    const uint32_t grid = (uint32_t)s->num_cus * 8;
+    static const int mult = getenv("CPH_STREAM_GRID_MULT") ? atoi(getenv("CPH_STREAM_GRID_MULT")) : 32;
+    const uint32_t grid = (uint32_t)s->num_cus * mult;
     CPH_LAUNCH(fastscan_stream_kernel, s->L.BW, s->L.D, dim3(grid), dim3(256), (size_t)s->L.PW * 16, st, a);
 }
 
@@ -779,7 +786,8 @@ int cph_fastscan_stream_create(int device, uint32_t D, uint32_t bits, uint64_t n
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->num_cus = prop.multiProcessorCount;
         s->d_blocks.alloc(n_blocks * s->L.stride + 64);
         s->d_mask.alloc(s->L.PW);
-        s->d_sink.alloc((size_t)s->num_cus * 8 * 4);
+        s->d_sink.alloc((size_t)s->num_cus * 64 * 4);
+        HIP_CHECK(hipMemset(s->d_sink.p, 0, s->d_sink.n * sizeof(float)));
         hipLaunchKernelGGL(stream_fill_kernel, dim3(s->num_cus * 16), dim3(64), 0, nullptr,
                            s->d_blocks.p, n_blocks, s->L, seed);
         HIP_CHECK(hipGetLastError());

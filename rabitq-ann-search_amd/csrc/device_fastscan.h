@@ -136,16 +136,101 @@ __device__ __forceinline__ void block_sums(const uint8_t* __restrict__ blk, cons
     }
 }
 
+// Issue/reduce split: with a compile-time D the code and aux loads of a block are issued
+// up front (so that the caller can put other independent loads and the estimated-set atomic
+// between issue and use); with a runtime D the loads happen inside reduce().
+template <int BW, int SD>
+struct BlockLoads {
+    static constexpr bool kStatic = (SD >= 128);
+    static constexpr int kT = kStatic ? BW * (SD / 32) : 4;          // dwords per neighbour
+    static constexpr int kNH = (kT / 4 >= 2) ? 2 : 1;
+    static constexpr int kCPL = kStatic ? kT / 4 / kNH : 1;          // 16-B chunks per lane
+    uint4 c[kCPL];
+    uint4 aux;
+
+    __device__ __forceinline__ void issue(const uint8_t* __restrict__ blk, const DevLayout& L, int lane) {
+        if constexpr (kStatic) {
+            const uint4* cp = reinterpret_cast<const uint4*>(blk) + (lane & (kNH * 32 - 1));
+#pragma unroll
+            for (int k = 0; k < kCPL; ++k) c[k] = cp[k * kNH * 32];
+        }
+        aux = reinterpret_cast<const uint4*>(blk + L.aux_off)[lane & 31];
+    }
+
+    __device__ __forceinline__ void reduce(const uint8_t* __restrict__ blk, const DevLayout& L,
+                                           const uint4* qm, int lane, LaneEst& o) {
+        if constexpr (kStatic) {
+            const int h = lane >> 5;
+            constexpr int PW = SD / 32;
+            if constexpr (BW >= 2) {
+                constexpr int PPH = BW / 2;
+                constexpr int G = PW / 4;
+                uint32_t S[PPH];
+#pragma unroll
+                for (int pl = 0; pl < PPH; ++pl) {
+                    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const uint4 cc = c[pl * G + g];
+                        acc4(cc.x, qm[4 * g + 0], a0, a1, a2, a3);
+                        acc4(cc.y, qm[4 * g + 1], a0, a1, a2, a3);
+                        acc4(cc.z, qm[4 * g + 2], a0, a1, a2, a3);
+                        acc4(cc.w, qm[4 * g + 3], a0, a1, a2, a3);
+                    }
+                    S[pl] = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+                }
+                uint32_t part = 0;
+#pragma unroll
+                for (int pl = 0; pl < PPH; ++pl) part += S[pl] << (BW - 1 - (h * PPH + pl));
+                o.nbit = part + __shfl_xor(part, 32);
+                const uint32_t s0_other = __shfl_xor(S[0], 32);
+                if constexpr (BW == 2) {
+                    const uint32_t s0 = h ? s0_other : S[0];
+                    const uint32_t s1 = h ? S[0] : s0_other;
+                    o.msb = s0;
+                    o.msb2 = 2 * s0 + s1;
+                } else {
+                    const uint32_t s1_other = __shfl_xor(S[1], 32);
+                    const uint32_t s0 = h ? s0_other : S[0];
+                    const uint32_t s1 = h ? s1_other : S[1];
+                    o.msb = s0;
+                    o.msb2 = 2 * s0 + s1;
+                }
+            } else {
+                uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                if (h < kNH) {
+#pragma unroll
+                    for (int k = 0; k < kCPL; ++k) {
+                        const uint4 cc = c[k];
+                        const uint32_t w0 = (h * kCPL + k) * 4;
+                        acc4(cc.x, qm[w0 + 0], a0, a1, a2, a3);
+                        acc4(cc.y, qm[w0 + 1], a0, a1, a2, a3);
+                        acc4(cc.z, qm[w0 + 2], a0, a1, a2, a3);
+                        acc4(cc.w, qm[w0 + 3], a0, a1, a2, a3);
+                    }
+                }
+                uint32_t sv = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+                const uint32_t ov = __shfl_xor(sv, 32);
+                sv = (kNH == 2) ? sv + ov : (h ? ov : sv);
+                o.nbit = o.msb = o.msb2 = sv;
+            }
+        } else {
+            block_sums<BW, SD>(blk, L, qm, lane, o.nbit, o.msb, o.msb2);
+        }
+        o.nop = __uint_as_float(aux.x);
+        o.ip_qo = __uint_as_float(aux.y);
+        o.ip_cp = __uint_as_float(aux.z);
+        o.pop = aux.w & 0xFFFFu;
+        o.wpop = aux.w >> 16;
+    }
+};
+
 template <int BW, int SD>
 __device__ __forceinline__ void load_block(const uint8_t* __restrict__ blk, const DevLayout& L,
                                            const uint4* qm, int lane, LaneEst& o) {
-    const uint4 aux = reinterpret_cast<const uint4*>(blk + L.aux_off)[lane & 31];
-    block_sums<BW, SD>(blk, L, qm, lane, o.nbit, o.msb, o.msb2);
-    o.nop = __uint_as_float(aux.x);
-    o.ip_qo = __uint_as_float(aux.y);
-    o.ip_cp = __uint_as_float(aux.z);
-    o.pop = aux.w & 0xFFFFu;
-    o.wpop = aux.w >> 16;
+    BlockLoads<BW, SD> b;
+    b.issue(blk, L, lane);
+    b.reduce(blk, L, qm, lane, o);
 }
 
 // Shared tail of the AVX2 vector paths fastscan_kernel.hpp:148-169 / :287-317.
@@ -220,12 +305,42 @@ __device__ __forceinline__ float group_reduce8(float c) {
     return b + __shfl_xor(b, 2);
 }
 
-// dot(q, v): q in LDS, v a global row; j = lane & 7.
+// N chain elements of lane j: loads first (all in flight together), then the FMA chain.
+template <int N>
+__device__ __forceinline__ void chain_load(const float* __restrict__ v, int j, float (&r)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = v[j + 8 * i];
+}
+template <int N>
+__device__ __forceinline__ float chain_dot(const float* q_lds, int j, const float (&r)[N], float c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) c = __fmaf_rn(q_lds[j + 8 * i], r[i], c);
+    return c;
+}
+template <int N>
+__device__ __forceinline__ float chain_l2(const float* q_lds, int j, const float (&r)[N], float c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float d = q_lds[j + 8 * i] - r[i];
+        c = __fmaf_rn(d, d, c);
+    }
+    return c;
+}
+
+// dot(q, v): q in LDS, v a global row; j = lane & 7.  128-element chunks keep 16 loads per
+// lane in flight per round trip.
 __device__ __forceinline__ float group_dot8(const float* q_lds, const float* __restrict__ v,
                                              uint32_t D, int j) {
     float c = 0.0f;
-#pragma unroll 4
-    for (uint32_t i = j; i < D; i += 8) c = __fmaf_rn(q_lds[i], v[i], c);
+    if (D >= 128) {
+        for (uint32_t base = 0; base < D; base += 128) {
+            float r[16];
+            chain_load<16>(v + base, j, r);
+            c = chain_dot<16>(q_lds + base, j, r, c);
+        }
+    } else {
+        for (uint32_t i = j; i < D; i += 8) c = __fmaf_rn(q_lds[i], v[i], c);
+    }
     return group_reduce8(c);
 }
 
@@ -233,10 +348,17 @@ __device__ __forceinline__ float group_dot8(const float* q_lds, const float* __r
 __device__ __forceinline__ float group_l2sq8(const float* q_lds, const float* __restrict__ v,
                                               uint32_t D, int j) {
     float c = 0.0f;
-#pragma unroll 4
-    for (uint32_t i = j; i < D; i += 8) {
-        float d = q_lds[i] - v[i];
-        c = __fmaf_rn(d, d, c);
+    if (D >= 128) {
+        for (uint32_t base = 0; base < D; base += 128) {
+            float r[16];
+            chain_load<16>(v + base, j, r);
+            c = chain_l2<16>(q_lds + base, j, r, c);
+        }
+    } else {
+        for (uint32_t i = j; i < D; i += 8) {
+            const float d = q_lds[i] - v[i];
+            c = __fmaf_rn(d, d, c);
+        }
     }
     return group_reduce8(c);
 }

@@ -48,9 +48,8 @@ struct SearchArgs {
     uint64_t cap;           // per-slot log/heap capacity
     uint64_t bm_words;      // per-slot bitmap words
     uint32_t* bitmaps;
-    uint2* heaps;           // {est bits, log slot}
-    uint32_t* log_ids;      // every newly estimated id, in discovery order
-    float* lowers;          // lower bound of pushed entries, indexed by log slot
+    uint4* beam;            // beam heap beyond the LDS-resident top levels (index = heap index)
+    uint32_t* log_ids;      // every newly estimated id, in discovery order (for un-marking)
     // outputs
     int64_t* out_ids;       // [nq][k]
     float* out_dist;        // [nq][k]
@@ -111,31 +110,58 @@ __device__ __forceinline__ void nn_sort(Result* h, uint32_t size) {  // std::sor
 }
 
 // Beam: std::priority_queue<BeamEntry, vector, greater> — a heap whose comparator is
-// "a.est > b.est" (rabitq_search.hpp:57,79-80).  Entries are {est bits, log slot}.
-__device__ __forceinline__ void beam_sift_up(uint2* h, uint32_t hole, uint32_t top, uint2 v) {
+// "a.est > b.est" (rabitq_search.hpp:57,79-80).  Structure-of-arrays {est, lower, id}; heap
+// indices below kBeamLds live in LDS (the levels every pop walks through), deeper ones in the
+// slot's global scratch.  Element movement is exactly libstdc++'s, wherever an index lives.
+constexpr uint32_t kBeamLds = 255;  // 8 full levels, 16 B per entry
+
+struct BeamEntry {
+    float est, lower;
+    uint32_t id;
+};
+
+struct Beam {
+    uint4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
+    uint4* g;   // global, [cap], indexed by heap index
+    __device__ __forceinline__ uint4 raw(uint32_t i) const { return i < kBeamLds ? l[i] : g[i]; }
+    __device__ __forceinline__ void put(uint32_t i, uint4 v) const {
+        if (i < kBeamLds) l[i] = v; else g[i] = v;
+    }
+    __device__ __forceinline__ BeamEntry get(uint32_t i) const {
+        const uint4 v = raw(i);
+        return BeamEntry{__uint_as_float(v.x), __uint_as_float(v.y), v.z};
+    }
+};
+
+__device__ __forceinline__ uint4 beam_pack(const BeamEntry& e) {
+    return make_uint4(__float_as_uint(e.est), __float_as_uint(e.lower), e.id, 0u);
+}
+
+__device__ __forceinline__ void beam_sift_up(const Beam& h, uint32_t hole, uint32_t top, uint4 v) {
     const float vk = __uint_as_float(v.x);
     while (hole > top) {
-        uint32_t p = (hole - 1) >> 1;
-        uint2 pv = h[p];
+        const uint32_t p = (hole - 1) >> 1;
+        const uint4 pv = h.raw(p);
         if (!(__uint_as_float(pv.x) > vk)) break;
-        h[hole] = pv;
+        h.put(hole, pv);
         hole = p;
     }
-    h[hole] = v;
+    h.put(hole, v);
 }
-__device__ __forceinline__ void beam_adjust(uint2* h, uint32_t hole, uint32_t len, uint2 v) {
+__device__ __forceinline__ void beam_adjust(const Beam& h, uint32_t hole, uint32_t len, uint4 v) {
     const uint32_t top = hole;
     uint32_t child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        uint2 r = h[child], l = h[child - 1];
-        if (__uint_as_float(r.x) > __uint_as_float(l.x)) { --child; r = l; }
-        h[hole] = r;
+        uint4 r = h.raw(child);
+        const uint4 lft = h.raw(child - 1);
+        if (__uint_as_float(r.x) > __uint_as_float(lft.x)) { --child; r = lft; }
+        h.put(hole, r);
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        h[hole] = h[child - 1];
+        h.put(hole, h.raw(child - 1));
         hole = child - 1;
     }
     beam_sift_up(h, hole, top, v);
@@ -149,13 +175,17 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | nn[k*8] | est[128] lower[128] exact[128]
-// ids[128] list[32] pad
+// ids[128] list[32+pad] | slack[128] | beam top levels (kBeamLds+1) x 16
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
-    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64;
+    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64 + 128 + 16 * (kBeamLds + 1) + 16;
 }
 
 template <int BW, int SD>
-__global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
+// 5 waves per SIMD (<= 96 VGPRs): measured best of {4,5,6,8} on MI355X
+#ifndef CPH_SEARCH_WAVES_PER_SIMD
+#define CPH_SEARCH_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int li = lane & 31;
@@ -170,13 +200,19 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
     float* s_exact = s_lower + 32;
     uint32_t* s_ids = reinterpret_cast<uint32_t*>(s_exact + 32);
     uint8_t* s_list = reinterpret_cast<uint8_t*>(s_ids + 32);
+    float* s_slack = reinterpret_cast<float*>(s_list + 64);
+    // 16-B aligned carve for the beam's LDS levels
+    uint4* s_beam = reinterpret_cast<uint4*>(
+        (reinterpret_cast<uintptr_t>(s_slack + 32) + 15) & ~static_cast<uintptr_t>(15));
 
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
-    uint2* heap = a.heaps + (size_t)slot * a.cap;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
-    float* lowers = a.lowers + (size_t)slot * a.cap;
+    Beam heap;
+    heap.l = s_beam;
+    heap.g = a.beam + (size_t)slot * a.cap;
     const float FMAX = 3.402823466e+38f;
+    if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
     for (;;) {
         uint32_t t = 0;
@@ -193,7 +229,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
         QP qp;
         qp.A = hd.A; qp.B = hd.B; qp.C = hd.C;
         qp.affine_a = a.sc.affine_a; qp.affine_b = a.sc.affine_b; qp.floor = a.sc.ip_qo_floor;
-        qp.slack = a.sc.slack[0];
+        qp.slack = s_slack[0];
         const float gamma = a.sc.gamma;
 
         // query_norm_sq = dot(q, q)  (:88)
@@ -214,6 +250,14 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
         int slack_batch = 0;
         bool overflow = false;
         unsigned long long st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
+        uint32_t pf_sink = 0;
+#ifdef CPH_PHASE_TIMERS
+        unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tlast = clock64();
+#define CPH_TICK(i) do { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define CPH_TICK(i) do {} while (0)
+#endif
 
         // entry: ep_est = exact_l2(ep); beam.push({ep_est, 0, ep}); mark estimated (:95-97)
         {
@@ -223,8 +267,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
             st_exact++;
             if (lane == 0) {
                 logi[0] = ep;
-                lowers[0] = 0.0f;
-                heap[0] = make_uint2(__float_as_uint(ex), 0u);
+                heap.put(0, beam_pack(BeamEntry{ex, 0.0f, ep}));
                 beam_size = 1;
                 atomicOr(&bm[ep >> 5], 1u << (ep & 31));
             }
@@ -234,19 +277,20 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
 
         for (;;) {
             // ---- pop + termination tests (lane 0) (:106-122) --------------------------
+            CPH_TICK(7);
             uint32_t state = 0;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
-            uint32_t cur_id = 0;
+            uint32_t cur_id = 0, next_id = 0;
             if (lane == 0) {
                 if (beam_size > 0) {
-                    uint2 top = heap[0];
+                    const BeamEntry top = heap.get(0);
                     if (beam_size > 1) {
-                        uint2 v = heap[beam_size - 1];
-                        beam_adjust(heap, 0, beam_size - 1, v);
+                        beam_adjust(heap, 0, beam_size - 1, heap.raw(beam_size - 1));
                     }
                     --beam_size;
-                    float cur_est = __uint_as_float(top.x);
-                    cur_id = logi[top.y];
-                    float cur_lower = lowers[top.y];
+                    const float cur_est = top.est;
+                    cur_id = top.id;
+                    next_id = beam_size ? heap.l[0].z : cur_id;
+                    const float cur_lower = top.lower;
                     float worst = nn_size ? nn[0].dist : FMAX;
                     if (nn_size >= k && cur_est >= gamma_q * worst) state = 0;
                     else if (nn_size >= k && cur_lower > worst) state = 1;
@@ -257,17 +301,49 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
             if (state == 0) break;
             if (state == 1) continue;
             cur_id = bcast_u32(cur_id);
+            next_id = bcast_u32(next_id);
+            CPH_TICK(0);
+
+            // ---- neighbour ids first: the estimated-set probe (:227) is a dependent round
+            // trip, so it is issued before the arithmetic on the block ----------------------
+            const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
+            const uint32_t nid = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
+            // ---- everything else this expansion reads is issued before the probe ----------
+            BlockLoads<BW, SD> bl;
+            bl.issue(blk, a.L, lane);
+            const float* vrow = a.raw + (size_t)cur_id * D;
+            const float cur_norm = a.norm_sq[cur_id];
+            float vr[16];
+            if constexpr (SD == 128) chain_load<16>(vrow, lane & 7, vr);
+            // keep the uses of `nid` behind the loads above: the wait for the ids must not
+            // serialise the block/vector loads behind it
+            __builtin_amdgcn_sched_barrier(0);
+            const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
+            const bool active = lane < 32 && valid;
+            uint32_t old_bits = 0;
+            const uint32_t my_bit = 1u << (nid & 31);
+            if (active) old_bits = atomicOr(&bm[nid >> 5], my_bit);
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
-            const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
-            LaneEst v;
-            load_block<BW, SD>(blk, a.L, qm, lane, v);
-            const uint32_t nid = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
-            const uint32_t count = *reinterpret_cast<const uint32_t*>(blk + a.L.count_off);
             float exact_dist;
             {
-                float dot = group_dot8(qv, a.raw + (size_t)cur_id * D, D, lane & 7);
-                exact_dist = exact_from_dot(qnorm, a.norm_sq[cur_id], dot);
+                float dot;
+                if constexpr (SD == 128) dot = group_reduce8(chain_dot<16>(qv, lane & 7, vr, 0.0f));
+                else dot = group_dot8(qv, vrow, D, lane & 7);
+                exact_dist = exact_from_dot(qnorm, cur_norm, dot);
+            }
+            LaneEst v;
+            bl.reduce(blk, a.L, qm, lane, v);
+            // warm the caches for the likely next expansion (the reference prefetches
+            // beam.top() too, :124-128): one dword per 64 B line of its block and vector
+            uint32_t pf = 0;
+            {
+                const uint32_t off = (uint32_t)lane * 64u;
+                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
+                if (off < a.L.stride) pf = *reinterpret_cast<const volatile uint32_t*>(nblk + off);
+                if (off < D * 4u)
+                    pf ^= *reinterpret_cast<const volatile uint32_t*>(
+                        reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D) + off);
             }
             st_exact++;
             st_exp++;
@@ -279,12 +355,13 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 if (lane == 0) w = nn_size ? nn[0].dist : FMAX;
                 worst0 = bcast_f32(w);
             }
-            if (count == 0) continue;  // (:137)
+            CPH_TICK(1);
+            if (!__any(active)) continue;  // n_neighbors == 0 (:137)
 
             // slack level schedule (:141-145)
             if (a.sc.num_slack > 0) {
                 int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
-                qp.slack = a.sc.slack[lvl];
+                qp.slack = s_slack[lvl];
                 ++slack_batch;
             }
             const float dqp = exact_dist;
@@ -296,7 +373,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 stage2_est<1>(qp, v, dqp, sq, est, lower);
             } else {
                 float lo1 = stage1_lower<BW>(qp, v, dqp, sq);
-                bool surv = (nn_sz < k) || (li < (int)count && lo1 < worst0);
+                bool surv = (nn_sz < k) || (valid && lo1 < worst0);
                 if (__any(surv)) {
                     stage2_est<BW>(qp, v, dqp, sq, est, lower);
                 } else {
@@ -306,14 +383,9 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 }
             }
 
-            // ---- estimated set: test-and-set in neighbour order (:227) ----------------
-            const bool active = lane < 32 && (uint32_t)lane < count;
-            bool is_new = false;
-            if (active) {
-                uint32_t bit = 1u << (nid & 31);
-                uint32_t old = atomicOr(&bm[nid >> 5], bit);
-                is_new = (old & bit) == 0;
-            }
+            CPH_TICK(2);
+            // ---- estimated set: result of the test-and-set issued above -------------------
+            bool is_new = active && (old_bits & my_bit) == 0;
             // a vertex whose neighbour list repeats an id: only the first copy is new
             if ((a.flags & 1u) && __any(is_new)) {
                 // (graphs written by the reference never repeat an id; the loader sets the
@@ -342,6 +414,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
             if (cand) s_list[__popc(cand_mask & ((1u << li) - 1u))] = (uint8_t)lane;
             st_new += n_new;
             __syncthreads();
+            CPH_TICK(3);
 
             // ---- speculative exact L2 of the candidates, 8 per pass -------------------
             {
@@ -358,6 +431,7 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 st_exact += n_cand;
             }
             __syncthreads();
+            CPH_TICK(4);
 
             // ---- serial replay of the neighbour loop (:218-273), lane 0 ---------------
             if (lane == 0) {
@@ -365,7 +439,6 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                 while (m) {
                     const int i = __ffs((int)m) - 1;
                     m &= m - 1;
-                    const uint32_t lslot = log_count + __popc(new_mask & ((1u << i) - 1u));
                     const uint32_t id_i = s_ids[i];
                     float worst = nn_size ? nn[0].dist : FMAX;
                     const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
@@ -405,15 +478,17 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
                         }
                     }
                     if (push) {
-                        lowers[lslot] = lo;
-                        beam_sift_up(heap, beam_size, 0, make_uint2(__float_as_uint(key), lslot));
+                        beam_sift_up(heap, beam_size, 0, beam_pack(BeamEntry{key, lo, id_i}));
                         ++beam_size;
                         ++st_push;
                     }
                 }
             }
+            CPH_TICK(5);
+            pf_sink ^= pf;  // consumed last: the prefetch never stalls the expansion itself
             log_count += n_new;
             __syncthreads();
+            CPH_TICK(6);
         }
 
         // ---- results (:276; src/bindings.cpp:202-210) ----------------------------------
@@ -439,6 +514,10 @@ __global__ __launch_bounds__(64) void search_kernel(SearchArgs a) {
             atomicAdd(&a.stats[2], st_new);
             atomicAdd(&a.stats[3], st_push);
             atomicAdd(&a.stats[4], st_skip);
+            if (pf_sink == 0x9E3779B9u) atomicAdd(&a.stats[7], 1ull);  // keeps the prefetch loads alive
+#ifdef CPH_PHASE_TIMERS
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);
+#endif
             if (overflow) atomicAdd(&a.stats[5], 1ull);
         }
         // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --

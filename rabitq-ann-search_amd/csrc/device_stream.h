@@ -39,10 +39,26 @@ __global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
     float acc = 0.0f;
     const uint64_t lo = a.out_est ? a.first : 0;
     const uint64_t hi = a.out_est ? a.first + a.count : a.n_blocks;
-    for (uint64_t b = lo + wave; b < hi; b += nwaves) {
+    // software pipeline: the next block's loads (codes, aux, ids) are in flight while the
+    // current block is reduced
+    BlockLoads<BW, SD> cur, nxt;
+    uint32_t cur_id = 0, nxt_id = 0;
+    uint64_t b = lo + wave;
+    if (b < hi) {
+        const uint8_t* blk = a.blocks + b * a.L.stride;
+        cur.issue(blk, a.L, lane);
+        cur_id = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[lane & 31];
+    }
+    for (; b < hi; b += nwaves) {
+        const uint64_t bn = b + nwaves;
+        if (bn < hi) {
+            const uint8_t* nblk = a.blocks + bn * a.L.stride;
+            nxt.issue(nblk, a.L, lane);
+            nxt_id = reinterpret_cast<const uint32_t*>(nblk + a.L.ids_off)[lane & 31];
+        }
         const uint8_t* blk = a.blocks + b * a.L.stride;
         LaneEst v;
-        load_block<BW, SD>(blk, a.L, qm, lane, v);
+        cur.reduce(blk, a.L, qm, lane, v);
         float est, lower;
         if constexpr (BW == 1) {
             stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
@@ -52,10 +68,13 @@ __global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
             stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
             acc += est + lower + lo1;
         }
+        if (cur_id == kInvalidNode) acc = 0.0f;  // the neighbour ids are part of the unit of work
         if (a.out_est && lane < 32) {
             a.out_est[(b - a.first) * 32 + lane] = est;
             a.out_lower[(b - a.first) * 32 + lane] = lower;
         }
+        cur = nxt;
+        cur_id = nxt_id;
     }
     for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
     if (lane == 0 && !a.out_est) a.sink[wave] = acc;
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(64) void block_hook_kernel(BlockHookArgs a) {
     __syncthreads();
     LaneEst v;
     load_block<BW, SD>(a.blk, a.L, qm, lane, v);
-    const uint32_t count = *reinterpret_cast<const uint32_t*>(a.blk + a.L.count_off);
+    const bool valid = reinterpret_cast<const uint32_t*>(a.blk + a.L.ids_off)[lane & 31] != kInvalidNode;
     const float sq = __builtin_sqrtf(a.dqp);
     float est, lower, lo1;
     if constexpr (BW == 1) {
@@ -94,7 +113,7 @@ __global__ __launch_bounds__(64) void block_hook_kernel(BlockHookArgs a) {
         lo1 = lower;
     } else {
         lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
-        bool surv = (!a.nn_full) || ((lane & 31) < (int)count && lo1 < a.worst);
+        bool surv = (!a.nn_full) || (valid && lo1 < a.worst);
         if (__any(surv)) {
             stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
         } else {

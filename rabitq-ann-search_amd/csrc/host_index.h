@@ -330,8 +330,16 @@ inline void repack_ref_to_dev(const uint8_t* ref_nb, const RefLayout& RL, const 
         a[3] = (uint32_t)pop[i] | ((uint32_t)(wpop ? wpop[i] : 0) << 16);
         std::memcpy(dev + L.aux_off + i * 16, a, 16);
     }
-    std::memcpy(dev + L.ids_off, ref_nb + RL.ids, 128);
-    std::memcpy(dev + L.count_off, ref_nb + RL.count, 4);
+    // slots >= count may hold stale ids in the file (graph_refinement.hpp:46-47); the device
+    // copy marks them invalid so that the kernels never need `count` on their critical path
+    uint32_t cnt;
+    std::memcpy(&cnt, ref_nb + RL.count, 4);
+    if (cnt > 32) cnt = 32;
+    uint32_t ids[32];
+    std::memcpy(ids, ref_nb + RL.ids, 128);
+    for (uint32_t i = cnt; i < 32; ++i) ids[i] = kInvalidNode;
+    std::memcpy(dev + L.ids_off, ids, 128);
+    std::memcpy(dev + L.count_off, &cnt, 4);
 }
 
 inline void repack_dev_to_ref(const uint8_t* dev, const DevLayout& L, const RefLayout& RL,
