@@ -65,10 +65,17 @@ int cph_size(cph_index* h, uint64_t* n);
 int cph_dim(cph_index* h, uint64_t* dim);
 int cph_is_finalized(cph_index* h, int* flag);
 
-/* Host-side construction.  Until it lands these return
- * CPH_NOT_IMPLEMENTED and indexes come from cph_load. */
+/* Index construction (api/hnsw_index.hpp:93-166).  build() copies the
+ * n x dim float32 vectors; finalize() builds the graph (exact 32-NN on the GPU, alpha-CNG
+ * pruning, per-edge RaBitQ codes, BFS reorder, upper layers, calibration).  Statistical, not
+ * bit-level, parity with the reference's builder (which depends on its thread count). */
 int cph_build(cph_index* h, const float* vectors, uint64_t n);
 int cph_finalize(cph_index* h);
+/* Construction hook: exact 32 nearest neighbours (squared L2, self excluded, ascending) of
+ * every row of vectors[n][dim] by GPU brute force — the working lists the reference obtains
+ * from NNDescent (graph/graph_refinement.hpp:455-515).  ids/dist: [n][32]. */
+int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, uint32_t* ids,
+                       float* dist);
 
 /* ---- search ---------------------------------------------------------------------- */
 /* queries: host, row-major [n][dim] float32.  ids/dist: host, [n][k], rows shorter than k

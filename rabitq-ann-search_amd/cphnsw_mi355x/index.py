@@ -166,6 +166,17 @@ class CPIndex:
         return out
 
 
+def knn_bruteforce(vectors, device=None):
+    """Exact 32-NN graph (ids uint32 [n,32], squared distances float32 [n,32]) on the GPU."""
+    v = _as_f32(vectors)
+    n, dim = v.shape
+    ids = np.zeros((n, 32), np.uint32)
+    dist = np.zeros((n, 32), np.float32)
+    dev = _default_device() if device is None else int(device)
+    _lib.check(_lib.lib().cph_knn_bruteforce(dev, v.ctypes.data, n, dim, ids.ctypes.data, dist.ctypes.data))
+    return ids, dist
+
+
 def _default_device():
     """One process per GPU: LOCAL_RANK selects the device when launched by torch.distributed.run."""
     import os

@@ -23,6 +23,7 @@
 #include "device_search.h"
 #include "device_stream.h"
 #include "host_index.h"
+#include "builder_pipeline.h"
 
 using namespace cph;
 
@@ -133,6 +134,9 @@ struct cph_index {
     uint32_t D = 0;
     int device = 0;
     bool finalized = false;
+    bool needs_build = false;          // build() done, finalize() pending
+    std::vector<float> pending;        // vectors handed to build()
+    uint64_t pending_n = 0;
     HostIndex host;
     DevLayout L{};
     SearchConsts sc{};
@@ -473,7 +477,7 @@ int cph_save(cph_index* h, const char* path) {
 }
 
 int cph_size(cph_index* h, uint64_t* n) {
-    return guarded([&] { *n = h->host.n; });
+    return guarded([&] { *n = h->needs_build ? h->pending_n : h->host.n; });
 }
 int cph_dim(cph_index* h, uint64_t* dim) {
     return guarded([&] { *dim = h->dim; });
@@ -482,15 +486,62 @@ int cph_is_finalized(cph_index* h, int* flag) {
     return guarded([&] { *flag = h->finalized ? 1 : 0; });
 }
 
-int cph_build(cph_index*, const float*, uint64_t) {
-    return fail(CPH_NOT_IMPLEMENTED,
-                "build() is host-side index construction (SURVEY.md §8f N2) and is not part of "
-                "this round's hot path; load() an index written by the reference instead.");
+int cph_build(cph_index* h, const float* vectors, uint64_t n) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        // api/hnsw_index.hpp:93-120: build() replaces any previous state
+        if (n == 0) throw InvalidArg("build requires at least one vector.");
+        if (!vectors) throw InvalidArg("null vectors");
+        h->use_device();
+        h->host = HostIndex();
+        h->finalized = false;
+        h->d_blocks.release(); h->d_raw.release(); h->d_norm.release();
+        h->pending.assign(vectors, vectors + n * h->dim);
+        h->pending_n = n;
+        h->needs_build = true;
+    });
 }
-int cph_finalize(cph_index*) {
-    return fail(CPH_NOT_IMPLEMENTED,
-                "finalize() is host-side index construction (SURVEY.md §8f N2) and is not part "
-                "of this round's hot path; load() an index written by the reference instead.");
+
+int cph_finalize(cph_index* h) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        // api/hnsw_index.hpp:122-166
+        const uint64_t n = h->needs_build ? h->pending_n : h->host.n;
+        if (n == 0) throw std::runtime_error("Cannot finalize an empty index.");
+        if (!h->needs_build) throw std::runtime_error("Finalize called without a pending build.");
+        if (n < 50) throw std::runtime_error("Calibration requires at least 50 nodes.");
+        if (n >= 0xFFFFFFFFull) throw InvalidArg("too many vectors");
+        h->use_device();
+        const bool verbose = getenv("CPH_BUILD_VERBOSE") != nullptr;
+        build::finalize_index(h->host, h->pending.data(), n, h->dim, h->D, h->bits, h->num_cus, verbose);
+        std::vector<float>().swap(h->pending);
+        h->pending_n = 0;
+        h->needs_build = false;
+        upload_index(h);
+        h->finalized = true;
+    });
+}
+
+int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, uint32_t* ids,
+                       float* dist) {
+    return guarded([&] {
+        if (!vectors || !ids || !dist || n == 0 || dim == 0) throw InvalidArg("bad arguments");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t D = std::max<size_t>(16, next_pow2(dim));
+        std::vector<float> x(n * D, 0.0f), nrm(n);
+        for (uint64_t i = 0; i < n; ++i) {
+            std::memcpy(&x[i * D], vectors + i * dim, dim * 4);
+            float s = 0.0f;
+            for (uint64_t j = 0; j < dim; ++j) s = std::fmaf(x[i * D + j], x[i * D + j], s);
+            nrm[i] = s;
+        }
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
+        build::gpu_knn(x.data(), nrm.data(), n, D, cus, ids, dist);
+    });
 }
 
 int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity) {

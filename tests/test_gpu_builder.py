@@ -1,0 +1,143 @@
+"""GPU tests of index construction: build()/finalize() of the drop-in.
+
+The reference's own build is not reproducible across thread counts, so parity here
+is (i) format/semantic: an index written by our builder loads in the compiled reference and the
+reference's CPU search on it equals our GPU search bit for bit, and (ii) statistical: graph
+quality (recall of the same search protocol) is not worse than the reference-built index'.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def sift_like(rng, n, dim, ncl):
+    cent = rng.gamma(2, 15, (ncl, dim))
+    X = cent[rng.integers(0, ncl, n)] + rng.normal(0, 12, (n, dim))
+    return np.clip(np.round(X), 0, 218).astype(np.float32), cent
+
+
+def brute_topk(X, Q, k):
+    d = (Q ** 2).sum(1)[:, None] + (X ** 2).sum(1)[None, :] - 2.0 * Q.astype(np.float64) @ X.T.astype(np.float64)
+    return np.argsort(d, axis=1)[:, :k]
+
+
+def dedup_recall(ids, raw_of_id, gt_rows, X, k=10):
+    """recall@k of the first k unique returned ids (ids are internal, with dups)."""
+    hits = 0
+    for q in range(len(ids)):
+        seen, uniq = set(), []
+        for i in ids[q]:
+            if i >= 0 and i not in seen:
+                seen.add(i)
+                uniq.append(i)
+            if len(uniq) == k:
+                break
+        got = {raw_of_id[i] for i in uniq}
+        hits += len(got & set(gt_rows[q][:k].tolist()))
+    return hits / (len(ids) * k)
+
+
+def index_rows(path, n, dim, D):
+    """internal id -> input row, recovered from the raw vectors stored in the file."""
+    off = 68 + 248 + 72 + dim * 4 + n * 4 + n * 4
+    raw = np.fromfile(path, dtype=np.float32, count=n * D, offset=off).reshape(n, D)[:, :dim]
+    return raw
+
+
+def test_knn_bruteforce_is_exact():
+    import cphnsw_mi355x
+    rng = np.random.default_rng(3)
+    for n, dim in ((1000, 128), (777, 96), (300, 10)):
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+        ids, d = cphnsw_mi355x.knn_bruteforce(X)
+        D2 = ((X[:, None, :].astype(np.float64) - X[None, :, :]) ** 2).sum(-1)
+        np.fill_diagonal(D2, np.inf)
+        want = np.sort(D2, axis=1)[:, :32]
+        assert np.allclose(d, want, rtol=1e-4, atol=1e-3), (n, dim)
+        got = np.take_along_axis(D2, ids.astype(np.int64), axis=1)
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-3)
+        assert (ids != np.arange(n)[:, None]).all()
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4])
+def test_built_index_is_valid_for_reference_and_search_matches(tmp_path, bits):
+    import cphnsw_mi355x
+    from oracle_lib import Oracle, ref_available, ref_module
+    rng = np.random.default_rng(11 + bits)
+    n, dim = 6000, 128
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((48, dim)).astype(np.float32)
+    ix = cphnsw_mi355x.CPIndex(dim, bits)
+    assert ix.size == 0 and not ix.is_finalized
+    ix.build(X)
+    assert ix.size == n and not ix.is_finalized
+    ix.finalize()
+    assert ix.is_finalized and ix.size == n
+    p = str(tmp_path / f"mine_{bits}.idx")
+    ix.save(p)
+    for k in (10, 50):
+        ids, d = ix.search_batch(Q, k)
+        oi = Oracle().load(p)
+        oids, od, _ = oi.search_batch(Q, k)
+        assert np.array_equal(ids, oids) and d.tobytes() == od.tobytes()
+        if ref_available():
+            r = ref_module().CPIndex(dim, bits)
+            r.load(p)                                   # the reference accepts our file
+            rids, rd = r.search_batch(Q, k)
+            assert np.array_equal(ids, rids) and d.tobytes() == rd.tobytes()
+    # a saved index round-trips through our own loader
+    ix2 = cphnsw_mi355x.CPIndex(dim, bits)
+    ix2.load(p)
+    ids2, d2 = ix2.search_batch(Q, 10)
+    ids1, d1 = ix.search_batch(Q, 10)
+    assert np.array_equal(ids1, ids2) and d1.tobytes() == d2.tobytes()
+
+
+def test_graph_quality_not_worse_than_reference(tmp_path):
+    import cphnsw_mi355x
+    from oracle_lib import ref_available, ref_module
+    if not ref_available():
+        pytest.skip("oracle/_ref not present")
+    rng = np.random.default_rng(5)
+    n, dim, bits = 20000, 128, 4
+    X, cent = sift_like(rng, n, dim, 20)
+    Q = (cent[rng.integers(0, 20, 200)] + rng.normal(0, 12, (200, dim))).astype(np.float32)
+    gt = brute_topk(X, Q, 10)
+    mine = cphnsw_mi355x.CPIndex(dim, bits)
+    mine.build(X)
+    mine.finalize()
+    pm = str(tmp_path / "mine.idx")
+    mine.save(pm)
+    ref = ref_module().CPIndex(dim, bits)
+    ref.build(X)
+    ref.finalize()
+    pr = str(tmp_path / "ref.idx")
+    ref.save(pr)
+
+    def rows_of(path):
+        raw = index_rows(path, n, dim, 128)
+        # map stored vectors back to input rows (duplicates map to any equal row: distances equal)
+        key = {X[i].tobytes(): i for i in range(n)}
+        return [key[raw[i].tobytes()] for i in range(n)]
+
+    ids_m, _ = mine.search_batch(Q, 20)
+    ids_r, _ = ref.search_batch(Q, 20)
+    rec_m = dedup_recall(ids_m, rows_of(pm), gt, X)
+    rec_r = dedup_recall(ids_r, rows_of(pr), gt, X)
+    print("recall@10 (dedup of k=20): ours", rec_m, "reference", rec_r)
+    assert rec_m >= rec_r - 0.05
+
+
+def test_build_errors():
+    import cphnsw_mi355x
+    ix = cphnsw_mi355x.CPIndex(128, 4)
+    with pytest.raises(RuntimeError, match="Cannot finalize an empty index"):
+        ix.finalize()
+    with pytest.raises(ValueError, match=r"vectors must be a \\(n, dim\\) float32 array"):
+        ix.build(np.zeros((10, 64), np.float32))
+    with pytest.raises(ValueError, match="at least one vector"):
+        ix.build(np.zeros((0, 128), np.float32))
+    ix.build(np.random.default_rng(0).standard_normal((30, 128)).astype(np.float32))
+    with pytest.raises(RuntimeError, match="at least 50 nodes"):
+        ix.finalize()
