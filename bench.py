@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): SIFT1M-class synthetic data, dim 128 (D=128), 4-bit RaBitQ
-codes, R=32, k=10.  A step = one `search_batch` pass of the layer-0 hot path over the rank's
-shard of a fixed query batch, queries resident in HBM, plus the RCCL all-gather of the
+Workload (BASELINE.json configs[1]): SIFT1M-class synthetic data, 1M x 128 (D=128), 4-bit RaBitQ
+codes, R=32, index built in-bench by this repo's builder (GPU exact 32-NN + host pruning/encoding).
+k = the smallest of {10,20,50,100} whose dedup recall@10 reaches 0.95 (the reference returns
+duplicate slots).  A step = one `search_batch` pass of the layer-0 hot path over the
+rank's shard of a fixed query batch, queries resident in HBM, plus the RCCL all-gather of the
 results.  Queries shard across ranks; the index is replicated (weak scaling: nq per GPU fixed).
 
 The JSON line also carries
@@ -47,37 +49,76 @@ def sift_like(rng, n, dim, ncl, centers=None):
     return np.clip(np.round(X), 0, 218).astype(np.float32), centers
 
 
-def make_data(n, nq, seed=1):
+def make_data(n, nq, seed=1, need_base=True):
+    """Queries are drawn first so that ranks that never touch the base vectors can skip them."""
     rng = np.random.default_rng(seed)
     ncl = max(10, n // 1000)
-    X, c = sift_like(rng, n, DIM, ncl)
-    Q, _ = sift_like(rng, nq, DIM, ncl, c)
+    centers = rng.gamma(2.0, 15.0, (ncl, DIM))
+    Q, _ = sift_like(rng, nq, DIM, ncl, centers)
+    X = None
+    if need_base:
+        X, _ = sift_like(rng, n, DIM, ncl, centers)
     return X, Q
 
 
-def get_index_file(args, rank, X):
-    """Index for the end-to-end leg.  Until the host-side builder lands the
-    index is produced by the compiled reference as part of the cpu_baseline leg (it has to
-    build it anyway to be timed on it) and handed to the GPU path as a v2 file."""
+def get_index_file(args, rank, X, local):
+    """Builds the C2 index with our own builder (GPU exact 32-NN + host pruning/encoding/calibration,
+    csrc/builder*.h) on rank 0 and hands it to every rank as a v2 file."""
     path = os.path.join(args.workdir, f"bench_n{args.n_index}_b{BITS}.idx")
-    info = {"builder": None, "build_s": None}
+    info = {"builder": "cphnsw_mi355x (this repo)", "build_s": None}
     if rank == 0 and not os.path.exists(path):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_lib import ref_available, ref_module
-        if not ref_available():
-            raise RuntimeError("no index builder available on this box (oracle/_ref missing)")
+        import cphnsw_mi355x
         t0 = time.time()
-        idx = ref_module().CPIndex(DIM, BITS)
+        idx = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
         idx.build(X)
         idx.finalize()
         idx.save(path + ".tmp")
         os.replace(path + ".tmp", path)
-        info = {"builder": "reference (cpu_baseline leg)", "build_s": round(time.time() - t0, 1)}
-        log(f"[bench] reference built n={args.n_index} in {info['build_s']} s")
+        del idx
+        info["build_s"] = round(time.time() - t0, 1)
+        log(f"[bench] built n={args.n_index} in {info['build_s']} s")
     return path, info
 
 
-def cpu_baseline(args, path, Q, stream):
+def ground_truth(X, Q, k, dev):
+    """Exact k-th nearest squared distances by brute force (torch fp32 GEMM on the GPU; plumbing for
+    the recall protocol only)."""
+    import torch
+    xb = torch.from_numpy(X).to(dev)
+    xn = (xb * xb).sum(1)
+    out = []
+    for lo in range(0, len(Q), 2048):
+        q = torch.from_numpy(Q[lo:lo + 2048]).to(dev)
+        d = (q * q).sum(1)[:, None] + xn[None, :] - 2.0 * (q @ xb.T)
+        out.append(torch.topk(d, k, dim=1, largest=False).values.clamp_min(0).cpu())
+    return torch.cat(out).numpy()
+
+
+def recall_at_10(ids, dist, gt_d, dedup):
+    """recall@10 by distance (tie-safe; ids are the reference's internal ids).
+    dedup=False: the first 10 returned slots as the reference returns them (duplicate slots count
+    once); dedup=True: the first 10 unique ids among the k returned."""
+    thr = gt_d[:, 9] * (1.0 + 1e-5) + 1e-3
+    hits = 0
+    for q in range(len(ids)):
+        seen = set()
+        h = 0
+        for j in range(ids.shape[1] if dedup else min(10, ids.shape[1])):
+            i = int(ids[q, j])
+            if i < 0:
+                break
+            if i in seen:
+                continue
+            seen.add(i)
+            if dist[q, j] <= thr[q]:
+                h += 1
+            if len(seen) == 10:
+                break
+        hits += min(h, 10)
+    return hits / (10.0 * len(ids))
+
+
+def cpu_baseline(args, path, Q, stream, K):
     """Reference (or port) on the host cores: bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, RefHooks, ref_available, ref_module
@@ -91,7 +132,7 @@ def cpu_baseline(args, path, Q, stream):
         t0 = time.time()
         idx.search_batch(sample_q, K)
         dt = time.time() - t0
-        out.update(kind="reference", value=len(sample_q) / dt, unit="qps")
+        out.update(kind="reference", value=len(sample_q) / dt, unit="queries/s")
         # streaming FastScan, same blocks and query as the GPU stream leg
         L = Oracle().layout(DIM, BITS)
         nb = min(stream.n_blocks, 200_000)
@@ -116,7 +157,7 @@ def cpu_baseline(args, path, Q, stream):
         t0 = time.time()
         oi.search_batch(sample_q, K, nthreads=cores)
         dt = time.time() - t0
-        out.update(kind="port", value=len(sample_q) / dt, unit="qps",
+        out.update(kind="port", value=len(sample_q) / dt, unit="queries/s",
                    sample=f"{len(sample_q)} queries, scalar oracle port, {cores} threads")
     return out
 
@@ -126,11 +167,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 100_000)))
+    ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 1_000_000)))
     ap.add_argument("--nq-per-gpu", type=int, default=10_000)
     ap.add_argument("--stream-blocks", type=int, default=1_000_000)
     ap.add_argument("--cpu-queries", type=int, default=2_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k", type=int, default=0, help="0 = smallest k in {10,20,50,100} with dedup recall@10 >= 0.95")
+    ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
     args = ap.parse_args()
 
@@ -153,8 +196,8 @@ def main():
 
     # ---- data, index ----------------------------------------------------------------------
     nq_total = args.nq_per_gpu * world
-    X, Q = make_data(args.n_index, nq_total)
-    path, build_info = get_index_file(args, rank, X)
+    X, Q = make_data(args.n_index, nq_total, need_base=(rank == 0))
+    path, build_info = get_index_file(args, rank, X, local)
     if world > 1:
         dist.barrier()
     index = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
@@ -163,8 +206,29 @@ def main():
     load_s = time.time() - t0
     q_shard = torch.from_numpy(Q[rank * args.nq_per_gpu:(rank + 1) * args.nq_per_gpu]).to(dev)
 
+    # ---- recall protocol (rank 0, outside the timed region) -> the k the metric is quoted at ----
+    recall = {}
+    k_run = args.k if args.k > 0 else 10
+    if rank == 0 and X is not None:
+        nrq = min(args.recall_queries, len(Q))
+        gt_d = ground_truth(X, Q[:nrq], 10, dev)
+        for kk in (10, 20, 50, 100):
+            ids_r, d_r = index.search_batch(Q[:nrq], kk)
+            recall[f"k{kk}_dedup"] = recall_at_10(ids_r, d_r, gt_d, True)
+            if kk == 10:
+                recall["k10_raw"] = recall_at_10(ids_r, d_r, gt_d, False)
+        if args.k == 0:
+            ok = [kk for kk in (10, 20, 50, 100) if recall[f"k{kk}_dedup"] >= 0.95]
+            k_run = ok[0] if ok else 10   # target unreachable for the reference algorithm here: its default k
+        log(f"[bench] recall@10: {recall} -> k={k_run}")
+    if world > 1:
+        kt = torch.tensor([k_run], device=dev)
+        dist.broadcast(kt, 0)
+        k_run = int(kt.item())
+    del X
+
     def step():
-        ids, d = index.search_batch_device(q_shard, K)
+        ids, d = index.search_batch_device(q_shard, k_run)
         return gather_results(ids, d, world)
 
     # ---- end-to-end search ----------------------------------------------------------------
@@ -195,18 +259,32 @@ def main():
     alg_bytes = stats["expansions"] * 32 * BYTES_PER_DIST + stats["exact_l2"] * BYTES_PER_EXACT
     achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
 
+    # k=10 (the reference's default k) for comparison when the metric k differs
+    qps_k10 = None
+    if k_run != 10:
+        for _ in range(2):
+            index.search_batch_device(q_shard, 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            index.search_batch_device(q_shard, 10)
+        torch.cuda.synchronize()
+        qps_k10 = args.nq_per_gpu * args.steps / (time.perf_counter() - t0)
+
     # ---- FastScan stream (metric part 2) -----------------------------------------------------
     stream = cphnsw_mi355x.FastScanStream(DIM, BITS, args.stream_blocks, seed=4, device=local)
     stream.run(300)          # ~150 ms of back-to-back passes: the chip reaches its steady clock
     ms, _ = stream.run(100)
     fs_dist_s = args.stream_blocks * 32 / (ms * 1e-3)
     fs_gbs = fs_dist_s * BYTES_PER_DIST / 1e9
+    # PMC-calibrated: the stream kernel fetches exactly n_blocks x stride bytes per pass
+    # (profiles/r1_pmc_summary.md); expressed like `achieved`
+    fs_traffic = args.stream_blocks * stream.block_bytes / (ms * 1e-3) / 1e9
 
-    out = None
     if rank == 0:
         ids_np = ids.cpu().numpy()
         out = {
-            "metric": "qps (search_batch, k=10) + fastscan_dist_per_s",
+            "metric": "qps (search_batch at the smallest k with dedup recall@10>=0.95, else k=10) + fastscan_dist_per_s",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -218,16 +296,21 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 popcount / f32",
             "data": "synthetic",
-            "config": {"workload": f"SIFT-like synthetic {args.n_index}x{DIM} f32 (int-valued, clustered), "
-                                   f"{BITS}-bit RaBitQ FastScan + exact-L2 rerank, R=32, k={K}",
-                       "n_index": args.n_index, "dim": DIM, "bits": BITS, "k": K,
+            "config": {"workload": f"SIFT1M-class synthetic {args.n_index}x{DIM} f32 (int-valued, clustered; "
+                                   f"SURVEY 8d C2), {BITS}-bit RaBitQ FastScan + exact-L2 rerank, R=32, "
+                                   f"k={k_run}, {args.nq_per_gpu} queries per GPU resident in HBM",
+                       "n_index": args.n_index, "dim": DIM, "bits": BITS, "k": k_run,
                        "nq_per_gpu": args.nq_per_gpu, "index_builder": build_info["builder"],
+                       "index_build_s": build_info["build_s"],
                        "parallelism": f"query-sharded x{world}, index replicated"},
+            "recall_at_10": recall,
+            "recall_target_met": bool(recall and recall.get(f"k{k_run}_dedup", 0.0) >= 0.95),
+            "qps_k10": qps_k10 if qps_k10 is not None else qps,
             "fastscan_stream": {"dist_per_s": fs_dist_s, "blocks": args.stream_blocks,
                                 "ms_per_pass": ms, "bytes_per_dist": BYTES_PER_DIST,
                                 "roofline": {"bound": "hbm", "achieved": fs_gbs, "peak": HBM_PEAK_GBS,
                                              "unit": "GB/s", "frac": fs_gbs / HBM_PEAK_GBS,
-                                             "traffic": None}},
+                                             "traffic": fs_traffic}},
             "roofline": {"bound": "hbm", "kernel": "search_kernel<4,128>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k_s * 1e3,
@@ -238,7 +321,7 @@ def main():
             "dup_slots_per_query": float((ids_np[:, 1:] == ids_np[:, :-1]).sum(1).mean()),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream)
+            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream, k_run)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

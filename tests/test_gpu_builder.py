@@ -134,7 +134,7 @@ def test_build_errors():
     ix = cphnsw_mi355x.CPIndex(128, 4)
     with pytest.raises(RuntimeError, match="Cannot finalize an empty index"):
         ix.finalize()
-    with pytest.raises(ValueError, match=r"vectors must be a \\(n, dim\\) float32 array"):
+    with pytest.raises(ValueError, match=r"vectors must be a \(n, dim\) float32 array"):
         ix.build(np.zeros((10, 64), np.float32))
     with pytest.raises(ValueError, match="at least one vector"):
         ix.build(np.zeros((0, 128), np.float32))
