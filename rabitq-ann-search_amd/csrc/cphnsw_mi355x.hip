@@ -21,6 +21,7 @@
 #include "device_encode.h"
 #include "device_fastscan.h"
 #include "device_search.h"
+#include "device_search2.h"
 #include "device_stream.h"
 #include "host_index.h"
 #include "builder_pipeline.h"
@@ -142,7 +143,8 @@ struct cph_index {
     SearchConsts sc{};
     uint32_t flags = 0;
     int num_cus = 256;
-    uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident query slots per CU (launch bounds of search_kernel)
+    uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident waves per CU (launch bounds of the search kernel)
+    int kernel_variant = 1;            // 1 = one query per wave (default, faster); 2 = two queries per wave
     // device-resident index
     DevBuf<uint8_t> d_blocks;
     DevBuf<float> d_raw, d_norm;
@@ -321,9 +323,15 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.status = h->d_status.p;
     a.stats = h->d_stats.p;
     HIP_CHECK(hipMemsetAsync(h->d_counter.p, 0, 4, st));
-    const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
-    if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
-    CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
+    if (h->kernel_variant == 2) {
+        const size_t lds = search2_lds_bytes(h->L.D, h->L.PW, k);
+        if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+        CPH_LAUNCH(search_kernel2, h->bits, h->L.D, dim3((slots + 1) / 2), dim3(64), lds, st, a);
+    } else {
+        const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
+        if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+        CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
+    }
 }
 
 // Core: queries already staged in d_queries/d_qmasks/d_qhdr; results into device buffers.
@@ -336,11 +344,13 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     h->d_stats.alloc(16);
     HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 128, st));
     // resident query slots: one wave each
-    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * h->waves_per_cu;
+    const uint32_t qpw = h->kernel_variant == 2 ? 2u : 1u;   // query slots per wave
+    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * h->waves_per_cu * qpw;
     // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
     // would leave 56% of the slots idle during the third round)
     const uint32_t rounds = (nq + max_slots - 1) / max_slots;
     uint32_t slots = std::min<uint32_t>(nq, (nq + rounds - 1) / rounds);
+    slots = (slots + qpw - 1) / qpw * qpw;
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
@@ -350,7 +360,7 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         // budget: at most 60% of what is free (plus what we already hold)
         const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots /= 2;
+        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots = slots / 2 / qpw * qpw;
         while (cap > 4096 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) cap /= 2;
         ensure_scratch(h, slots, cap);
     } else {
@@ -379,6 +389,7 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
             1, std::min<uint64_t>(todo.size(), (uint64_t)((free_b + held) * 0.6) / per));
         h->d_bitmaps.release(); h->d_logids.release(); h->d_beam.release();
         h->scratch_slots = 0; h->scratch_cap = 0;
+        s2 = (s2 + qpw - 1) / qpw * qpw;
         ensure_scratch(h, s2, full);
         h->d_todo.alloc(todo.size());
         HIP_CHECK(hipMemcpyAsync(h->d_todo.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
@@ -442,6 +453,8 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         h->device = device;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+        if (const char* e = getenv("CPH_SEARCH_KERNEL")) h->kernel_variant = atoi(e) == 2 ? 2 : 1;
+        if (h->kernel_variant == 2) h->waves_per_cu = 4 * CPH_SEARCH2_WAVES_PER_SIMD;
         if (const char* e = getenv("CPH_WAVES_PER_CU")) h->waves_per_cu = (uint32_t)std::max(1, atoi(e));
         *out = h;
     });
