@@ -186,8 +186,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CPH_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL rehearsal
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     os.makedirs(args.workdir, exist_ok=True)
 
@@ -198,7 +202,7 @@ def main():
     nq_total = args.nq_per_gpu * world
     X, Q = make_data(args.n_index, nq_total, need_base=(rank == 0))
     path, build_info = get_index_file(args, rank, X, local)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     index = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
     t0 = time.time()
@@ -221,7 +225,7 @@ def main():
             ok = [kk for kk in (10, 20, 50, 100) if recall[f"k{kk}_dedup"] >= 0.95]
             k_run = ok[0] if ok else 10   # target unreachable for the reference algorithm here: its default k
         log(f"[bench] recall@10: {recall} -> k={k_run}")
-    if world > 1:
+    if use_dist:
         kt = torch.tensor([k_run], device=dev)
         dist.broadcast(kt, 0)
         k_run = int(kt.item())
@@ -229,14 +233,15 @@ def main():
 
     def step():
         ids, d = index.search_batch_device(q_shard, k_run)
-        return gather_results(ids, d, world)
+        return gather_results(ids, d, world, force=use_dist)
 
     # ---- end-to-end search ----------------------------------------------------------------
+    log(f"[bench] rank {rank}: timed region, k={k_run}")
     for _ in range(args.warmup):
         step()
     kernel_us = []
     stats = None
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -245,14 +250,15 @@ def main():
         stats = index.last_search_stats()
         kernel_us.append(stats["kernel_us"])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = nq_total * args.steps / elapsed
+    log(f"[bench] rank {rank}: {qps:.0f} q/s")
 
     # roofline of the dominant kernel (persistent search kernel), rank 0's launches
     k_s = float(np.mean(kernel_us)) * 1e-6
@@ -320,10 +326,10 @@ def main():
             "index_load_s": load_s,
             "dup_slots_per_query": float((ids_np[:, 1:] == ids_np[:, :-1]).sum(1).mean()),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, path, Q, stream, k_run)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,9 +15,9 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_results(ids, dist_t, world, group=None):
+def gather_results(ids, dist_t, world, group=None, force=False):
     """All-gather equal-sized result shards (torch tensors) along dim 0."""
-    if world == 1:
+    if world == 1 and not force:
         return ids, dist_t
     import torch
     import torch.distributed as dist
