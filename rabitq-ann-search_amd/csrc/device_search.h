@@ -177,7 +177,7 @@ __device__ __forceinline__ float bcast_f32(float v) {
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | nn[k*8] | est[128] lower[128] exact[128]
 // ids[128] list[32+pad] | slack[128] | beam top levels (kBeamLds+1) x 16
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
-    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64 + 128 + 16 * (kBeamLds + 1) + 16;
+    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64 + 128 + 16 + 16 * (kBeamLds + 1) + 16;
 }
 
 template <int BW, int SD>
@@ -201,9 +201,10 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
     uint32_t* s_ids = reinterpret_cast<uint32_t*>(s_exact + 32);
     uint8_t* s_list = reinterpret_cast<uint8_t*>(s_ids + 32);
     float* s_slack = reinterpret_cast<float*>(s_list + 64);
+    double* s_ratio = reinterpret_cast<double*>(s_slack + 32);   // [2], 8-B aligned (offsets are multiples of 16)
     // 16-B aligned carve for the beam's LDS levels
     uint4* s_beam = reinterpret_cast<uint4*>(
-        (reinterpret_cast<uintptr_t>(s_slack + 32) + 15) & ~static_cast<uintptr_t>(15));
+        (reinterpret_cast<uintptr_t>(s_slack + 32 + 4) + 15) & ~static_cast<uintptr_t>(15));
 
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
@@ -243,13 +244,14 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         // lane-0 serial state
         uint32_t beam_size = 0, nn_size = 0;
         float gamma_q = gamma;
-        double ratio_sum = 0.0, ratio_sq_sum = 0.0;
-        unsigned long long ratio_count = 0;
+        // gamma-adaptation running sums live in LDS (touched only when a neighbour is reranked)
+        if (lane == 0) { s_ratio[0] = 0.0; s_ratio[1] = 0.0; }
+        uint32_t ratio_count = 0;
         // uniform state
         uint32_t log_count = 0;
         int slack_batch = 0;
         bool overflow = false;
-        unsigned long long st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
+        uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
         uint32_t pf_sink = 0;
 #ifdef CPH_PHASE_TIMERS
         unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -406,81 +408,82 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             const uint32_t my_rank = __popc(new_mask & ((1u << li) - 1u));
             if (log_count + n_new > a.cap) { overflow = true; break; }
             if (is_new) logi[log_count + my_rank] = nid;
-            if (lane < 32) {
-                s_est[lane] = est;
-                s_lower[lane] = lower;
-                s_ids[lane] = nid;
-            }
-            if (cand) s_list[__popc(cand_mask & ((1u << li) - 1u))] = (uint8_t)lane;
             st_new += n_new;
-            __syncthreads();
             CPH_TICK(3);
 
-            // ---- speculative exact L2 of the candidates, 8 per pass -------------------
-            {
+            // ---- speculative exact L2 of the candidates, 8 per pass (rare: ~0.15 per expansion) --
+            if (cand_mask) {
+                if (cand) s_list[__popc(cand_mask & ((1u << li) - 1u))] = (uint8_t)lane;
+                __syncthreads();
                 const uint32_t n_cand = __popc(cand_mask);
                 const int g = lane >> 3;
                 for (uint32_t base = 0; base < n_cand; base += 8) {
                     const bool have = base + g < n_cand;
                     const uint32_t idx = have ? s_list[base + g] : 0;
-                    const uint32_t cid = have ? s_ids[idx] : cur_id;
+                    const uint32_t cid_l = (uint32_t)__shfl((int)nid, (int)idx);
+                    const uint32_t cid = have ? cid_l : cur_id;
                     float dot = group_dot8(qv, a.raw + (size_t)cid * D, D, lane & 7);
                     float ex = exact_from_dot(qnorm, a.norm_sq[cid], dot);
                     if (have && (lane & 7) == 0) s_exact[idx] = ex;
                 }
                 st_exact += n_cand;
+                __syncthreads();
             }
-            __syncthreads();
             CPH_TICK(4);
 
-            // ---- serial replay of the neighbour loop (:218-273), lane 0 ---------------
-            if (lane == 0) {
+            // ---- serial replay of the neighbour loop (:218-273).  The loop runs on lane 0 (heap
+            // state lives there) but `i` comes from the wave-uniform ballot mask, so neighbour i's
+            // est / lower / id are read straight out of lane i's registers with v_readlane ------
+            {
                 uint32_t m = new_mask;
                 while (m) {
                     const int i = __ffs((int)m) - 1;
                     m &= m - 1;
-                    const uint32_t id_i = s_ids[i];
-                    float worst = nn_size ? nn[0].dist : FMAX;
-                    const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
-                    float key, lo;
-                    bool push = false;
-                    if (warmup) {
-                        const float ex = s_exact[i];
-                        nn_push(nn, nn_size, k, Result{id_i, ex});
-                        if (ex < dabs) { push = true; key = ex; lo = ex; }
-                    } else {
-                        const float e = s_est[i];
-                        lo = s_lower[i];
-                        if (lo >= worst) continue;
-                        if (e < worst) {
+                    const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
+                    const float e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i));
+                    const float lo_i = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i));
+                    if (lane == 0) {
+                        float worst = nn_size ? nn[0].dist : FMAX;
+                        const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
+                        float key = 0.0f, lo = lo_i;
+                        bool push = false;
+                        if (warmup) {
                             const float ex = s_exact[i];
                             nn_push(nn, nn_size, k, Result{id_i, ex});
-                            if (ex < dabs) { push = true; key = ex; }
-                            if (ex > kEpsSmall) {
-                                // gamma adaptation (:255-267), fused as the reference compiles it
-                                double r = (double)(e / ex);
-                                ratio_sum += r;
-                                ratio_sq_sum = fma(r, r, ratio_sq_sum);
-                                ++ratio_count;
-                                if (ratio_count >= a.sc.gamma_warmup) {
-                                    double cnt = (double)ratio_count;
-                                    double mean = ratio_sum / cnt;
-                                    double var = fma(-mean, mean, ratio_sq_sum / cnt);
-                                    double sd = sqrt(var < 0.0 ? 0.0 : var);
-                                    float gq = gamma * (float)fma((double)a.sc.gamma_beta, sd, 1.0);
-                                    gamma_q = (gq < gamma) ? gamma
-                                                           : ((a.sc.gamma_max < gq) ? a.sc.gamma_max : gq);
+                            if (ex < dabs) { push = true; key = ex; lo = ex; }
+                        } else if (!(lo_i >= worst)) {
+                            if (e < worst) {
+                                const float ex = s_exact[i];
+                                nn_push(nn, nn_size, k, Result{id_i, ex});
+                                if (ex < dabs) { push = true; key = ex; }
+                                if (ex > kEpsSmall) {
+                                    // gamma adaptation (:255-267), fused as the reference compiles it
+                                    double r = (double)(e / ex);
+                                    const double rs = s_ratio[0] + r;
+                                    const double rq = fma(r, r, s_ratio[1]);
+                                    s_ratio[0] = rs;
+                                    s_ratio[1] = rq;
+                                    ++ratio_count;
+                                    if (ratio_count >= a.sc.gamma_warmup) {
+                                        double cnt = (double)ratio_count;
+                                        double mean = rs / cnt;
+                                        double var = fma(-mean, mean, rq / cnt);
+                                        double sd = sqrt(var < 0.0 ? 0.0 : var);
+                                        float gq = gamma * (float)fma((double)a.sc.gamma_beta, sd, 1.0);
+                                        gamma_q = (gq < gamma) ? gamma
+                                                               : ((a.sc.gamma_max < gq) ? a.sc.gamma_max : gq);
+                                    }
                                 }
+                            } else if (e < dabs) {
+                                push = true;
+                                key = e;
                             }
-                        } else if (e < dabs) {
-                            push = true;
-                            key = e;
                         }
-                    }
-                    if (push) {
-                        beam_sift_up(heap, beam_size, 0, beam_pack(BeamEntry{key, lo, id_i}));
-                        ++beam_size;
-                        ++st_push;
+                        if (push) {
+                            beam_sift_up(heap, beam_size, 0, beam_pack(BeamEntry{key, lo, id_i}));
+                            ++beam_size;
+                            ++st_push;
+                        }
                     }
                 }
             }
@@ -509,11 +512,11 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         if (lane == 0) {
             a.out_count[qi] = nn_final;
             a.status[qi] = overflow ? kStatusOverflow : kStatusOk;
-            atomicAdd(&a.stats[0], st_exp);
-            atomicAdd(&a.stats[1], st_exact);
-            atomicAdd(&a.stats[2], st_new);
-            atomicAdd(&a.stats[3], st_push);
-            atomicAdd(&a.stats[4], st_skip);
+            atomicAdd(&a.stats[0], (unsigned long long)st_exp);
+            atomicAdd(&a.stats[1], (unsigned long long)st_exact);
+            atomicAdd(&a.stats[2], (unsigned long long)st_new);
+            atomicAdd(&a.stats[3], (unsigned long long)st_push);
+            atomicAdd(&a.stats[4], (unsigned long long)st_skip);
             if (pf_sink == 0x9E3779B9u) atomicAdd(&a.stats[7], 1ull);  // keeps the prefetch loads alive
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);

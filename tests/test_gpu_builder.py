@@ -60,12 +60,12 @@ def test_knn_bruteforce_is_exact():
         assert (ids != np.arange(n)[:, None]).all()
 
 
-@pytest.mark.parametrize("bits", [1, 2, 4])
-def test_built_index_is_valid_for_reference_and_search_matches(tmp_path, bits):
+@pytest.mark.parametrize("bits,n,dim", [(1, 6000, 128), (2, 6000, 128), (4, 6000, 128), (4, 2500, 960),
+                                        (2, 3000, 96), (4, 1200, 10)])
+def test_built_index_is_valid_for_reference_and_search_matches(tmp_path, bits, n, dim):
     import cphnsw_mi355x
     from oracle_lib import Oracle, ref_available, ref_module
-    rng = np.random.default_rng(11 + bits)
-    n, dim = 6000, 128
+    rng = np.random.default_rng(11 + bits + dim)
     X = rng.standard_normal((n, dim)).astype(np.float32)
     Q = rng.standard_normal((48, dim)).astype(np.float32)
     ix = cphnsw_mi355x.CPIndex(dim, bits)

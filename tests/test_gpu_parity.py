@@ -239,3 +239,15 @@ print("OK")
     out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + code], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_large_k_against_oracle(cph, oracle, gold):
+    """k far above the default (result heap of 500 entries in LDS): still bit-exact."""
+    for name, bits in (("g128", 4), ("g16", 1)):
+        ix = _load(cph, name, bits)
+        oi = oracle.load(fixture_path(name, bits))
+        Q = gold[f"Q/{name}"][:8]
+        for k in (257, 500):
+            ids, d = ix.search_batch(Q, k)
+            oids, od, _ = oi.search_batch(Q, k)
+            assert np.array_equal(ids, oids) and _beq(d, od), (name, bits, k)
