@@ -106,11 +106,7 @@ void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, s
     for (auto& x : th) x.join();
 }
 
-// kernel dispatch over (bits, static D)
-template <template <int, int> class K, class Args>
-void dispatch(uint32_t bits, uint32_t D, dim3 grid, dim3 block, size_t lds, hipStream_t st,
-              const Args& a);
-
+// kernel dispatch over (bits, static D): D == 128 gets the fully unrolled instantiation
 #define CPH_LAUNCH(KERNEL, bits, D, grid, block, lds, st, args)                                   \
     do {                                                                                          \
         const bool s128 = (D) == 128;                                                             \
