@@ -22,6 +22,7 @@
 #include "device_fastscan.h"
 #include "device_search.h"
 #include "device_search2.h"
+#include "device_search4.h"
 #include "device_stream.h"
 #include "host_index.h"
 #include "builder_pipeline.h"
@@ -140,7 +141,7 @@ struct cph_index {
     uint32_t flags = 0;
     int num_cus = 256;
     uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident waves per CU (launch bounds of the search kernel)
-    int kernel_variant = 1;            // 1 = one query per wave (default, faster); 2 = two queries per wave
+    int kernel_variant = 1;            // 1 = LDS heaps, one query per wave; 2 = two queries per wave; 4 = register heaps
     // device-resident index
     DevBuf<uint8_t> d_blocks;
     DevBuf<float> d_raw, d_norm;
@@ -319,7 +320,10 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.status = h->d_status.p;
     a.stats = h->d_stats.p;
     HIP_CHECK(hipMemsetAsync(h->d_counter.p, 0, 4, st));
-    if (h->kernel_variant == 2) {
+    if (h->kernel_variant == 4 && k <= kRegNn) {
+        const size_t lds = search4_lds_bytes(h->L.D, h->L.PW);
+        CPH_LAUNCH(search_kernel4, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
+    } else if (h->kernel_variant == 2) {
         const size_t lds = search2_lds_bytes(h->L.D, h->L.PW, k);
         if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
         CPH_LAUNCH(search_kernel2, h->bits, h->L.D, dim3((slots + 1) / 2), dim3(64), lds, st, a);
@@ -449,7 +453,8 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         h->device = device;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
-        if (const char* e = getenv("CPH_SEARCH_KERNEL")) h->kernel_variant = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("CPH_SEARCH_KERNEL")) { int v = atoi(e); h->kernel_variant = (v == 2 || v == 4) ? v : 1; }
+        if (h->kernel_variant == 4) h->waves_per_cu = 4 * CPH_SEARCH4_WAVES_PER_SIMD;
         if (h->kernel_variant == 2) h->waves_per_cu = 4 * CPH_SEARCH2_WAVES_PER_SIMD;
         if (const char* e = getenv("CPH_WAVES_PER_CU")) h->waves_per_cu = (uint32_t)std::max(1, atoi(e));
         *out = h;
