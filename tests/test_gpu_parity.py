@@ -211,9 +211,11 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
-def test_two_queries_per_wave_kernel_is_bit_exact(gold):
-    """The alternative search kernel (two queries per wavefront) against the same goldens.
-    A fresh process is needed because the variant is chosen at cph_create time from the env."""
+@pytest.mark.parametrize("variant", ["2", "4"])
+def test_alternative_search_kernels_are_bit_exact(gold, variant):
+    """The alternative search kernels (2 = two queries per wavefront, 4 = register-resident heaps on
+    the scalar unit) against the same goldens.  A fresh process is needed because the variant is
+    chosen at cph_create time from the environment."""
     import subprocess
     import sys
     import os
@@ -235,19 +237,7 @@ for name, spec in DATASETS.items():
 print("OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CPH_SEARCH_KERNEL="2")
+    env = dict(os.environ, CPH_SEARCH_KERNEL=variant)
     out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + code], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
-
-
-def test_large_k_against_oracle(cph, oracle, gold):
-    """k far above the default (result heap of 500 entries in LDS): still bit-exact."""
-    for name, bits in (("g128", 4), ("g16", 1)):
-        ix = _load(cph, name, bits)
-        oi = oracle.load(fixture_path(name, bits))
-        Q = gold[f"Q/{name}"][:8]
-        for k in (257, 500):
-            ids, d = ix.search_batch(Q, k)
-            oids, od, _ = oi.search_batch(Q, k)
-            assert np.array_equal(ids, oids) and _beq(d, od), (name, bits, k)
