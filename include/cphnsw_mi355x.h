@@ -94,6 +94,11 @@ int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, ui
 int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
                uint64_t* m);
 
+/* Stored vectors of internal ids [first, first+count) (dim floats each, row-major).  The reference
+ * never exposes its BFS permutation; a harness recovers internal -> input row numbers by
+ * matching these rows against its own base vectors. */
+int cph_get_vectors(cph_index* h, uint64_t first, uint64_t count, float* out);
+
 /* Tuning knobs (0 = automatic): resident query slots and per-slot beam capacity. */
 int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
 

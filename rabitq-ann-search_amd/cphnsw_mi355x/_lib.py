@@ -25,6 +25,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "cph_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                              C.POINTER(C.c_uint64)]),
+    "cph_get_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "cph_set_search_params": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "cph_last_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cph_encode_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

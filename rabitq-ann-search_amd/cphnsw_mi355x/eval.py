@@ -1,0 +1,103 @@
+"""Benchmark harness with the reference's protocol and JSON schema (cphnsw/eval.py:31-119): for each
+bit-width build + finalize, one warm-up `search_batch`, `n_runs` timed calls, median time,
+qps = nq / median, recall@1/10/100, ADR, written to <output_dir>/<dataset>_results.json.
+
+Two things the reference's harness gets wrong are corrected here and reported next to the
+like-for-like numbers: returned ids are internal post-reorder ids, so they are mapped
+back to input rows before they are compared with the ground truth (`recall_at_*`, `adr`); and the
+top-k contains duplicate slots, so `recall_at_10_dedup` scores the first 10 *unique* ids of the k
+returned.  `recall_at_*_as_reference` is what the reference's own code would print (unmapped ids).
+"""
+import gc
+import json
+import time
+from pathlib import Path
+
+import numpy as np
+
+from .datasets import load_dataset
+from .index import CPIndex
+
+BIT_WIDTHS = (1, 2, 4)
+ADR_K = 10
+
+
+def recall_at_k(results, ground_truth, k):
+    kk = min(k, results.shape[1], ground_truth.shape[1])
+    hit = (results[:, :kk, None] == ground_truth[:, None, :kk]).any(axis=2)
+    return float(hit.sum(axis=1).mean()) / kk
+
+
+def dedup_first(ids, k):
+    """First k unique non-negative ids of every row, padded with -1."""
+    out = np.full((ids.shape[0], k), -1, np.int64)
+    for r in range(ids.shape[0]):
+        seen, j = set(), 0
+        for v in ids[r]:
+            if v >= 0 and v not in seen:
+                seen.add(v)
+                out[r, j] = v
+                j += 1
+                if j == k:
+                    break
+    return out
+
+
+def _rss_mb():
+    try:
+        import psutil
+        return psutil.Process().memory_info().rss / 2 ** 20
+    except Exception:
+        return 0.0
+
+
+def run_benchmark(dataset_name, base_dir, k, n_runs, output_dir, bit_widths=BIT_WIDTHS, device=None):
+    ds = load_dataset(dataset_name, Path(base_dir))
+    base, queries, gt, dim = ds["base"], ds["queries"], ds["groundtruth"].astype(np.int64), ds["dim"]
+    adr_k = min(k, ADR_K, gt.shape[1])
+    gt_d = ((base[gt[:, :adr_k]] - queries[:, None, :]) ** 2).sum(axis=2)
+    results = []
+    for bits in bit_widths:
+        gc.collect()
+        rss0 = _rss_mb()
+        t0 = time.perf_counter()
+        index = CPIndex(dim, bits, device=device)
+        index.build(base)
+        index.finalize()
+        build_s = time.perf_counter() - t0
+        gc.collect()
+        mem_mb = _rss_mb() - rss0
+        index.search_batch(queries, k)                      # warm-up
+        times, ids = [], None
+        for _ in range(max(1, n_runs)):
+            t0 = time.perf_counter()
+            ids, _ = index.search_batch(queries, k)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        rows = index.internal_to_input_rows(base)
+        mapped = np.where(ids >= 0, rows[np.maximum(ids, 0)], -1)
+        res_d = ((base[np.maximum(mapped[:, :adr_k], 0)] - queries[:, None, :]) ** 2).sum(axis=2)
+        results.append({
+            "algorithm": f"cphnsw-mi355x-{bits}bit",
+            "build_time_s": round(build_s, 2),
+            "memory_mb": round(mem_mb, 1),
+            "recall_at_1": round(recall_at_k(mapped, gt, 1), 4),
+            "recall_at_10": round(recall_at_k(mapped, gt, min(k, 10)), 4),
+            "recall_at_100": round(recall_at_k(mapped, gt, min(k, 100)), 4),
+            "recall_at_10_dedup": round(recall_at_k(dedup_first(mapped, min(k, 10)), gt, min(k, 10)), 4),
+            "recall_at_10_as_reference": round(recall_at_k(ids, gt, min(k, 10)), 4),
+            "adr": round(float(np.mean(res_d / np.maximum(gt_d, 1e-30))), 6),
+            "qps": round(len(queries) / med, 1),
+            "median_latency_us": round(med / len(queries) * 1e6, 2),
+            "search_stats": index.last_search_stats(),
+        })
+        del index
+        gc.collect()
+    out = {"metadata": {"timestamp": time.strftime("%Y-%m-%dT%H:%M:%S"), "dataset": dataset_name,
+                        "n_base": int(len(base)), "n_queries": int(len(queries)), "dim": dim, "metric": "l2",
+                        "k": k, "n_runs": n_runs},
+           "results": results}
+    Path(output_dir).mkdir(parents=True, exist_ok=True)
+    with (Path(output_dir) / f"{dataset_name}_results.json").open("w") as f:
+        json.dump(out, f, indent=2)
+    return out

@@ -126,6 +126,28 @@ class CPIndex:
                 "rerun_queries", "kernel_us", "slots_cap")
         return dict(zip(keys, [int(x) for x in out]))
 
+    def get_vectors(self, first=0, count=None):
+        """Stored vectors of internal ids [first, first+count) as float32 (count, dim)."""
+        if count is None:
+            count = self.size - first
+        out = np.empty((count, self._dim), np.float32)
+        _lib.check(_lib.lib().cph_get_vectors(self._h, int(first), int(count), out.ctypes.data))
+        return out
+
+    def internal_to_input_rows(self, base, chunk=1 << 18):
+        """int64[size]: input row number of every internal id, by exact row matching.
+        Rows that occur several times in `base` map to one of their equal copies."""
+        base = _as_f32(base)
+        key = {}
+        for i in range(base.shape[0] - 1, -1, -1):
+            key[base[i].tobytes()] = i
+        out = np.empty(self.size, np.int64)
+        for lo in range(0, self.size, chunk):
+            v = self.get_vectors(lo, min(chunk, self.size - lo))
+            for j in range(v.shape[0]):
+                out[lo + j] = key[v[j].tobytes()]
+        return out
+
     # kernel-level hooks (parity tests)
     def encode_query(self, query):
         q = _as_f32(query)

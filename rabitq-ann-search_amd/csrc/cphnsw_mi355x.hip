@@ -558,6 +558,17 @@ int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t di
     });
 }
 
+int cph_get_vectors(cph_index* h, uint64_t first, uint64_t count, float* out) {
+    return guarded([&] {
+        if (!h || !out) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        if (first + count > h->host.n) throw InvalidArg("vector range out of bounds");
+        for (uint64_t i = 0; i < count; ++i)
+            std::memcpy(out + i * h->dim, h->host.vec(first + i), h->dim * sizeof(float));
+    });
+}
+
 int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity) {
     return guarded([&] {
         std::lock_guard<std::mutex> lk(h->mu);

@@ -1,0 +1,52 @@
+"""Benchmark harness: loaders on CPU, the full protocol on the GPU."""
+import json
+
+import numpy as np
+import pytest
+
+
+def test_vecs_roundtrip(tmp_path):
+    from cphnsw_mi355x.datasets import read_vecs, write_vecs
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((37, 24)).astype(np.float32)
+    g = rng.integers(0, 1000, (37, 100)).astype(np.int32)
+    write_vecs(tmp_path / "a.fvecs", a)
+    write_vecs(tmp_path / "g.ivecs", g)
+    assert np.array_equal(read_vecs(tmp_path / "a.fvecs", np.float32), a)
+    assert np.array_equal(read_vecs(tmp_path / "g.ivecs", np.int32), g)
+
+
+def test_recall_helpers():
+    from cphnsw_mi355x.eval import dedup_first, recall_at_k
+    ids = np.array([[3, 3, 5, 5, 7, -1], [1, 2, 3, 4, 5, 6]])
+    assert dedup_first(ids, 3).tolist() == [[3, 5, 7], [1, 2, 3]]
+    gt = np.array([[3, 5, 9], [9, 9, 9]])
+    assert recall_at_k(dedup_first(ids, 3), gt, 3) == pytest.approx((2 / 3 + 0) / 2)
+
+
+@pytest.mark.gpu
+def test_run_benchmark_end_to_end(tmp_path):
+    from cphnsw_mi355x.datasets import write_vecs
+    from cphnsw_mi355x.eval import run_benchmark
+    rng = np.random.default_rng(4)
+    n, dim, nq = 4000, 128, 100
+    cent = rng.gamma(2, 15, (8, dim))
+    base = np.clip(np.round(cent[rng.integers(0, 8, n)] + rng.normal(0, 12, (n, dim))), 0, 218).astype(np.float32)
+    q = np.clip(np.round(cent[rng.integers(0, 8, nq)] + rng.normal(0, 12, (nq, dim))), 0, 218).astype(np.float32)
+    d = ((q[:, None, :].astype(np.float64) - base[None]) ** 2).sum(-1)
+    gt = np.argsort(d, axis=1, kind="stable")[:, :100].astype(np.int32)
+    root = tmp_path / "data" / "sift1m"
+    root.mkdir(parents=True)
+    write_vecs(root / "sift_base.fvecs", base)
+    write_vecs(root / "sift_query.fvecs", q)
+    write_vecs(root / "sift_groundtruth.ivecs", gt)
+    out = run_benchmark("sift1m", tmp_path / "data", k=100, n_runs=2, output_dir=tmp_path / "res", bit_widths=(4,))
+    r = out["results"][0]
+    for key in ("build_time_s", "memory_mb", "recall_at_1", "recall_at_10", "recall_at_100", "adr", "qps",
+                "median_latency_us"):
+        assert key in r
+    assert r["qps"] > 0 and r["adr"] >= 1.0 - 1e-6
+    assert r["recall_at_10_dedup"] >= r["recall_at_10"] - 1e-9   # duplicates can only hurt the raw score
+    assert r["recall_at_100"] > 0.2
+    saved = json.loads((tmp_path / "res" / "sift1m_results.json").read_text())
+    assert saved["metadata"]["n_base"] == n and saved["metadata"]["k"] == 100
