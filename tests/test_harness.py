@@ -45,7 +45,8 @@ def test_run_benchmark_end_to_end(tmp_path):
     for key in ("build_time_s", "memory_mb", "recall_at_1", "recall_at_10", "recall_at_100", "adr", "qps",
                 "median_latency_us"):
         assert key in r
-    assert r["qps"] > 0 and r["adr"] >= 1.0 - 1e-6
+    # ADR can fall below 1: duplicate result slots repeat a near neighbour against a farther GT rank (F2)
+    assert r["qps"] > 0 and 0.5 < r["adr"] < 2.0
     assert r["recall_at_10_dedup"] >= r["recall_at_10"] - 1e-9   # duplicates can only hurt the raw score
     assert r["recall_at_100"] > 0.2
     saved = json.loads((tmp_path / "res" / "sift1m_results.json").read_text())
