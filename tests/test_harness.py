@@ -47,7 +47,7 @@ def test_run_benchmark_end_to_end(tmp_path):
         assert key in r
     # ADR can fall below 1: duplicate result slots repeat a near neighbour against a farther GT rank (F2)
     assert r["qps"] > 0 and 0.5 < r["adr"] < 2.0
-    assert r["recall_at_10_dedup"] >= r["recall_at_10"] - 1e-9   # duplicates can only hurt the raw score
+    assert 0.0 < r["recall_at_10_dedup"] <= 1.0   # (the raw score double-counts duplicate hits, F2)
     assert r["recall_at_100"] > 0.2
     saved = json.loads((tmp_path / "res" / "sift1m_results.json").read_text())
     assert saved["metadata"]["n_base"] == n and saved["metadata"]["k"] == 100
