@@ -118,7 +118,7 @@ def recall_at_10(ids, dist, gt_d, dedup):
     return hits / (10.0 * len(ids))
 
 
-def cpu_baseline(args, path, Q, stream, K):
+def cpu_baseline(args, path, Q, stream, K, gpu_index=None):
     """Reference (or port) on the host cores: bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, RefHooks, ref_available, ref_module
@@ -133,6 +133,14 @@ def cpu_baseline(args, path, Q, stream, K):
         idx.search_batch(sample_q, K)
         dt = time.time() - t0
         out.update(kind="reference", value=len(sample_q) / dt, unit="queries/s")
+        if gpu_index is not None:
+            # full-size parity: the reference's CPU results on this index vs the GPU's, bit for bit
+            r_ids, r_d = idx.search_batch(sample_q, K)
+            g_ids, g_d = gpu_index.search_batch(sample_q, K)
+            out["parity_vs_reference"] = {
+                "queries": int(len(sample_q)), "k": int(K),
+                "ids_identical": bool(np.array_equal(r_ids, g_ids)),
+                "distances_bit_identical": bool(r_d.tobytes() == g_d.tobytes())}
         # streaming FastScan, same blocks and query as the GPU stream leg
         L = Oracle().layout(DIM, BITS)
         nb = min(stream.n_blocks, 200_000)
@@ -165,8 +173,8 @@ def cpu_baseline(args, path, Q, stream, K):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 1_000_000)))
     ap.add_argument("--nq-per-gpu", type=int, default=10_000)
     ap.add_argument("--stream-blocks", type=int, default=1_000_000)
@@ -327,7 +335,7 @@ def main():
             "dup_slots_per_query": float((ids_np[:, 1:] == ids_np[:, :-1]).sum(1).mean()),
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream, k_run)
+            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream, k_run, index)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
