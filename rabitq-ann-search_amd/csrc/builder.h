@@ -44,7 +44,8 @@ struct Cand {
 };
 
 inline void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
-    unsigned hw = std::thread::hardware_concurrency();
+    // default: at most 64 host threads per process (one process per GPU, eight per node)
+    unsigned hw = std::min(64u, std::thread::hardware_concurrency());
     size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n / std::max<size_t>(min_chunk, 1)));
     if (const char* e = getenv("CPH_BUILD_THREADS")) nt = std::max(1, atoi(e));
     if (nt <= 1) { fn(0, n); return; }

@@ -94,7 +94,8 @@ struct DevBuf {
 };
 
 void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
-    unsigned hw = std::thread::hardware_concurrency();
+    // at most 64 host threads per process: eight ranks share one node (one process per GPU)
+    unsigned hw = std::min(64u, std::thread::hardware_concurrency());
     size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n / std::max<size_t>(min_chunk, 1)));
     if (nt <= 1) { fn(0, n); return; }
     std::vector<std::thread> th;
