@@ -353,12 +353,26 @@ inline void finalize_index(HostIndex& hi, const float* vecs, size_t n, size_t di
     // ---- first pass keeps the working lists (<= R candidates: no pruning, :535-536), then the
     // reverse-edge pass (:386-429) prunes own + reverse candidates with alpha-CNG ------------
     const float err_tol = 1.0f / std::sqrt(static_cast<float>(D));
+    // exact edge lengths in the reference's summation order (the GPU distances served only to rank)
+    parallel_for(n, 256, [&](size_t lo, size_t hi_) {
+        for (size_t u = lo; u < hi_; ++u)
+            for (int s = 0; s < kKnnK; ++s) {
+                const uint32_t v = knn_ids[u * kKnnK + s];
+                if (v != kInvalidNode) knn_d[u * kKnnK + s] = l2sq(D, vec((uint32_t)u), vec(v));
+            }
+    });
     std::vector<std::vector<Cand>> rev(n);
+    {
+        std::vector<uint32_t> indeg(n, 0);
+        for (size_t e = 0; e < n * (size_t)kKnnK; ++e)
+            if (knn_ids[e] != kInvalidNode) ++indeg[knn_ids[e]];
+        for (size_t v = 0; v < n; ++v) rev[v].reserve(indeg[v]);
+    }
     for (size_t u = 0; u < n; ++u)
         for (int s = 0; s < kKnnK; ++s) {
             const uint32_t v = knn_ids[u * kKnnK + s];
             if (v == kInvalidNode) continue;
-            rev[v].push_back({(uint32_t)u, l2sq(D, vec((uint32_t)u), vec(v))});
+            rev[v].push_back({(uint32_t)u, knn_d[u * kKnnK + s]});
         }
     std::vector<uint32_t> nbr(n * R, kInvalidNode);
     std::vector<uint8_t> nbr_cnt(n, 0);
@@ -368,7 +382,7 @@ inline void finalize_index(HostIndex& hi, const float* vecs, size_t n, size_t di
             for (int s = 0; s < kKnnK; ++s) {
                 const uint32_t w = knn_ids[i * kKnnK + s];
                 if (w == kInvalidNode) continue;
-                all.push_back({w, l2sq(D, vec((uint32_t)i), vec(w))});
+                all.push_back({w, knn_d[i * kKnnK + s]});
             }
             std::vector<Cand> sel;
             if (rev[i].empty()) {
