@@ -154,6 +154,17 @@ int cph_fastscan_stream_eval(cph_stream* s, uint64_t first, uint64_t count, floa
                              float* lower);
 int cph_fastscan_stream_destroy(cph_stream* s);
 
+/* ---- host-only hooks (no HIP call; used by the CPU test tier) --------------------------------- */
+/* Reads a v2 index file with the library's reader and writes it back with its writer. */
+int cph_host_rewrite_index(const char* path_in, const char* path_out);
+/* Repacks one reference-layout neighbour block (distance/fastscan_layout.hpp:51-155) into the device
+ * layout (dev_block, *dev_bytes bytes) and back into `ref_roundtrip`. */
+int cph_host_repack_block(uint32_t D, uint32_t bits, const uint8_t* ref_block, uint8_t* dev_block,
+                          uint64_t* dev_bytes, uint8_t* ref_roundtrip);
+/* Host mirror of the query encoder (the device encoder is cph_encode_query): lut u8[D/4][16],
+ * coeffs[3], masks u32[max(1,D/32)][4] (the bit-sliced form the kernels consume). */
+int cph_host_encode_query(uint64_t dim, const float* query, uint8_t* lut, float* coeffs, uint32_t* masks);
+
 #ifdef __cplusplus
 }
 #endif

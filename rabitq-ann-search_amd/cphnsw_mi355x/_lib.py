@@ -33,6 +33,9 @@ SYMBOLS = {
     "cph_fastscan_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cph_exact_l2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cph_host_rewrite_index": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "cph_host_repack_block": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    "cph_host_encode_query": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cph_fastscan_stream_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "cph_fastscan_stream_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -287,7 +287,7 @@ inline void finalize_index(HostIndex& hi, const float* vecs, size_t n, size_t di
         }
     }
     std::vector<std::vector<UpperEdge>> layers(max_level);
-    UpperBuilder ub{raw.data(), D, n, M_UPPER, levels, layers, max_level, entry};
+    UpperBuilder ub{raw.data(), D, n, M_UPPER, levels, layers, max_level, entry, 0.0f, 1.2f, {}, 0};
     ub.run();
     note("upper layers");
 

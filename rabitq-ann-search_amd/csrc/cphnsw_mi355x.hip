@@ -751,6 +751,58 @@ int cph_exact_l2(cph_index* h, const float* query, const uint32_t* ids, uint64_t
 
 }  // extern "C"
 
+// ---- host-only hooks -------------------------------------------------------------------------
+extern "C" {
+
+int cph_host_rewrite_index(const char* path_in, const char* path_out) {
+    return guarded([&] {
+        if (!path_in || !path_out) throw InvalidArg("null argument");
+        // peek the header for the parameters a handle would carry
+        FILE* f = std::fopen(path_in, "rb");
+        if (!f) throw std::runtime_error(std::string("Cannot open file for reading: ") + path_in);
+        uint8_t hdr[28];
+        const size_t got = std::fread(hdr, 1, sizeof(hdr), f);
+        std::fclose(f);
+        if (got != sizeof(hdr)) throw std::runtime_error(std::string("Read error or truncated file: ") + path_in);
+        uint32_t D, bw, dim;
+        std::memcpy(&D, hdr + 12, 4); std::memcpy(&bw, hdr + 20, 4); std::memcpy(&dim, hdr + 24, 4);
+        HostIndex hi;
+        hi.load(path_in, D, bw, dim);
+        hi.save(path_out);
+    });
+}
+
+int cph_host_repack_block(uint32_t D, uint32_t bits, const uint8_t* ref_block, uint8_t* dev_block,
+                          uint64_t* dev_bytes, uint8_t* ref_roundtrip) {
+    return guarded([&] {
+        if (bits != 1 && bits != 2 && bits != 4) throw InvalidArg("bits must be 1, 2 or 4");
+        if (D < 16 || D > 2048 || (D & (D - 1))) throw InvalidArg("D must be a power of two in 16..2048");
+        const DevLayout L = make_dev_layout(D, bits);
+        const RefLayout RL = make_ref_layout(D, bits);
+        repack_ref_to_dev(ref_block, RL, L, dev_block);
+        if (dev_bytes) *dev_bytes = L.stride;
+        if (ref_roundtrip) repack_dev_to_ref(dev_block, L, RL, ref_roundtrip);
+    });
+}
+
+int cph_host_encode_query(uint64_t dim, const float* query, uint8_t* lut, float* coeffs, uint32_t* masks) {
+    return guarded([&] {
+        const size_t D = std::max<size_t>(16, next_pow2(dim));
+        if (dim == 0 || D > 2048) throw InvalidArg("unsupported dimension");
+        Rotation rot;
+        rot.init(D, 42);
+        std::vector<float> buf(D, 0.0f);
+        std::memcpy(buf.data(), query, dim * sizeof(float));
+        EncodedQuery eq;
+        encode_query(rot, buf.data(), eq);
+        if (lut) qu_to_lut(eq.qu.data(), D, lut);
+        if (coeffs) { coeffs[0] = eq.A; coeffs[1] = eq.B; coeffs[2] = eq.C; }
+        if (masks) qu_to_masks(eq.qu.data(), D, masks);
+    });
+}
+
+}  // extern "C"
+
 // ---- streaming FastScan benchmark object ---------------------------------------------------
 struct cph_stream {
     int device = 0;
