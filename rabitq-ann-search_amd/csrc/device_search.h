@@ -120,12 +120,34 @@ struct BeamEntry {
     uint32_t id;
 };
 
+// The LDS part is addressed through address-space-3 pointers so that every access is a ds_*
+// instruction (a generic pointer would make them flat_* accesses, which also wait on vmcnt).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) float lds_f32;
+
 struct Beam {
-    uint4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
-    uint4* g;   // global, [cap], indexed by heap index
-    __device__ __forceinline__ uint4 raw(uint32_t i) const { return i < kBeamLds ? l[i] : g[i]; }
+    lds_u32x4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
+    uint4* g;       // global, [cap], indexed by heap index
+    __device__ __forceinline__ uint4 lds(uint32_t i) const {
+        const u32x4 t = l[i];
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+    __device__ __forceinline__ void lds_put(uint32_t i, uint4 v) const {
+        u32x4 t;
+        t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+        l[i] = t;
+    }
+    __device__ __forceinline__ float lds_key(uint32_t i) const {
+        return reinterpret_cast<lds_f32*>(l)[4 * i];
+    }
+    __device__ __forceinline__ uint4 raw(uint32_t i) const {
+        uint4 v;
+        if (i < kBeamLds) v = lds(i); else v = g[i];
+        return v;
+    }
     __device__ __forceinline__ void put(uint32_t i, uint4 v) const {
-        if (i < kBeamLds) l[i] = v; else g[i] = v;
+        if (i < kBeamLds) lds_put(i, v); else g[i] = v;
     }
     __device__ __forceinline__ BeamEntry get(uint32_t i) const {
         const uint4 v = raw(i);
@@ -167,6 +189,57 @@ __device__ __forceinline__ void beam_adjust(const Beam& h, uint32_t hole, uint32
     beam_sift_up(h, hole, top, v);
 }
 
+// std::pop_heap of a beam that lives entirely in LDS (size <= kBeamLds), executed by the whole
+// wave instead of one lane.  The element movement is libstdc++'s __adjust_heap + __push_heap
+// (same comparisons, same operand order, so ties and NaNs resolve identically); only the
+// schedule differs: every internal node's "which child moves up" comparison is evaluated at
+// once (lane j <-> nodes j and j+64, one ballot each), the root-to-leaf path is then walked on
+// wave-uniform bit masks with no memory access, and the moves along the path are one parallel
+// LDS read plus one parallel write.  Two LDS round trips instead of one dependent round trip
+// per heap level.  Returns the id at the new top.
+__device__ __forceinline__ uint32_t beam_pop_wave(const Beam& h, uint32_t size, int lane) {
+    const uint32_t len = size - 1;                // heap length once the last element is taken out
+    const uint4 v = h.lds(len);                   // the value __adjust_heap re-inserts
+    const uint32_t nint = (len - 1) >> 1;         // nodes j < nint have both children below len
+    bool b0 = false, b1 = false;                  // true: the left child moves up
+    if ((uint32_t)lane < nint) b0 = h.lds_key(2 * lane + 2) > h.lds_key(2 * lane + 1);
+    const unsigned long long m0 = __ballot(b0);
+    unsigned long long m1 = 0;
+    if (nint > 64) {
+        if ((uint32_t)lane + 64 < nint) b1 = h.lds_key(2 * lane + 130) > h.lds_key(2 * lane + 129);
+        m1 = __ballot(b1);
+    }
+    uint32_t hole = 0, d = 0;
+    uint32_t my_dst = 0, my_src = 0;              // lane t moves entry p_{t+1} into p_t
+    while (hole < nint) {
+        const unsigned long long m = hole < 64 ? m0 : m1;
+        const uint32_t left = (uint32_t)(m >> (hole & 63)) & 1u;
+        const uint32_t child = 2 * hole + 2 - left;
+        if ((uint32_t)lane == d) { my_dst = hole; my_src = child; }
+        hole = child;
+        ++d;
+    }
+    if ((len & 1) == 0 && hole == (len - 2) >> 1) {   // a last node with a left child only
+        const uint32_t child = 2 * hole + 1;
+        if ((uint32_t)lane == d) { my_dst = hole; my_src = child; }
+        hole = child;
+        ++d;
+    }
+    uint4 e = make_uint4(0, 0, 0, 0);
+    bool c = false;                                // __push_heap: parent (now e_t) > v -> parent moves down
+    if ((uint32_t)lane < d) {
+        e = h.lds(my_src);
+        c = __uint_as_float(e.x) > __uint_as_float(v.x);
+    }
+    const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
+    const uint32_t fin = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;   // v ends at p_fin
+    if ((uint32_t)lane < fin) h.lds_put(my_dst, e);
+    if (fin == d) { if (lane == 0) h.lds_put(hole, v); }
+    else if ((uint32_t)lane == fin) h.lds_put(my_dst, v);
+    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+    return fin == 0 ? v.z : e0;
+}
+
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -202,9 +275,9 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
     uint8_t* s_list = reinterpret_cast<uint8_t*>(s_ids + 32);
     float* s_slack = reinterpret_cast<float*>(s_list + 64);
     double* s_ratio = reinterpret_cast<double*>(s_slack + 32);   // [2], 8-B aligned (offsets are multiples of 16)
-    // 16-B aligned carve for the beam's LDS levels
-    uint4* s_beam = reinterpret_cast<uint4*>(
-        (reinterpret_cast<uintptr_t>(s_slack + 32 + 4) + 15) & ~static_cast<uintptr_t>(15));
+    // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
+    const uint32_t beam_off = (uint32_t)((PW * 16 + D * 4 + k * 8 + 4 * 128 + 64 + 128 + 16 + 15) & ~15u);
+    lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
 
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
@@ -241,7 +314,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             qnorm = group_reduce8(c);
         }
 
-        // lane-0 serial state
+        // wave-uniform heap sizes (re-broadcast after every lane-0 section)
         uint32_t beam_size = 0, nn_size = 0;
         float gamma_q = gamma;
         // gamma-adaptation running sums live in LDS (touched only when a neighbour is reranked)
@@ -270,9 +343,9 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             if (lane == 0) {
                 logi[0] = ep;
                 heap.put(0, beam_pack(BeamEntry{ex, 0.0f, ep}));
-                beam_size = 1;
                 atomicOr(&bm[ep >> 5], 1u << (ep & 31));
             }
+            beam_size = 1;
             log_count = 1;
         }
         __syncthreads();
@@ -280,30 +353,34 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         for (;;) {
             // ---- pop + termination tests (lane 0) (:106-122) --------------------------
             CPH_TICK(7);
-            uint32_t state = 0;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
-            uint32_t cur_id = 0, next_id = 0;
-            if (lane == 0) {
-                if (beam_size > 0) {
-                    const BeamEntry top = heap.get(0);
-                    if (beam_size > 1) {
-                        beam_adjust(heap, 0, beam_size - 1, heap.raw(beam_size - 1));
+            if (beam_size == 0) break;
+            uint32_t cur_id, next_id;
+            {
+                const uint4 topv = heap.lds(0);
+                cur_id = bcast_u32(topv.z);
+                if (beam_size > 1) {
+                    if (beam_size <= kBeamLds) {
+                        next_id = beam_pop_wave(heap, beam_size, lane);
+                    } else {
+                        if (lane == 0) beam_adjust(heap, 0, beam_size - 1, heap.raw(beam_size - 1));
+                        __builtin_amdgcn_wave_barrier();
+                        next_id = heap.lds(0).z;
                     }
-                    --beam_size;
-                    const float cur_est = top.est;
-                    cur_id = top.id;
-                    next_id = beam_size ? heap.l[0].z : cur_id;
-                    const float cur_lower = top.lower;
-                    float worst = nn_size ? nn[0].dist : FMAX;
-                    if (nn_size >= k && cur_est >= gamma_q * worst) state = 0;
-                    else if (nn_size >= k && cur_lower > worst) state = 1;
-                    else state = 2;
+                    next_id = bcast_u32(next_id);
+                } else {
+                    next_id = cur_id;
                 }
+                --beam_size;
+                const float cur_est = __uint_as_float(topv.x);
+                const float cur_lower = __uint_as_float(topv.y);
+                const float worst = nn_size ? nn[0].dist : FMAX;
+                uint32_t verdict = 2;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
+                if (nn_size >= k && cur_est >= gamma_q * worst) verdict = 0;
+                else if (nn_size >= k && cur_lower > worst) verdict = 1;
+                verdict = bcast_u32(verdict);   // every lane read the same words: make it provably uniform
+                if (verdict == 0) break;
+                if (verdict == 1) continue;
             }
-            state = bcast_u32(state);
-            if (state == 0) break;
-            if (state == 1) continue;
-            cur_id = bcast_u32(cur_id);
-            next_id = bcast_u32(next_id);
             CPH_TICK(0);
 
             // ---- neighbour ids first: the estimated-set probe (:227) is a dependent round
@@ -350,13 +427,10 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             st_exact++;
             st_exp++;
             if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
-            const uint32_t nn_sz = bcast_u32(nn_size);
-            float worst0;
-            {
-                float w = 0.0f;
-                if (lane == 0) w = nn_size ? nn[0].dist : FMAX;
-                worst0 = bcast_f32(w);
-            }
+            nn_size = bcast_u32(nn_size);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nn_sz = nn_size;
+            const float worst0 = bcast_f32(nn_sz ? nn[0].dist : FMAX);
             CPH_TICK(1);
             if (!__any(active)) continue;  // n_neighbors == 0 (:137)
 
@@ -400,7 +474,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             }
             const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
             const bool warmup = nn_sz < k;  // (:210)
-            bool cand = is_new && (warmup || (lower < worst0 && est < worst0));
+            bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
             const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
 
             // log new ids (discovery order = neighbour order)
@@ -434,7 +508,25 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             // ---- serial replay of the neighbour loop (:218-273).  The loop runs on lane 0 (heap
             // state lives there) but `i` comes from the wave-uniform ballot mask, so neighbour i's
             // est / lower / id are read straight out of lane i's registers with v_readlane ------
-            {
+            if (!warmup && cand_mask == 0) {
+                // No neighbour of this vertex is reranked, so the result heap, its threshold and
+                // gamma_q stay what they were at loop entry: every decision of the serial loop is
+                // `lower < worst0 <= est < gamma_q * worst0` and can be taken by all lanes at once;
+                // only the beam pushes themselves keep neighbour order.
+                const float dabs0 = gamma_q * worst0;
+                const bool p = is_new && !(lower >= worst0) && est < dabs0;
+                uint32_t pm = (uint32_t)(__ballot(p) & 0xFFFFFFFFull);
+                while (pm) {
+                    const int i = __ffs((int)pm) - 1;
+                    pm &= pm - 1;
+                    const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
+                    const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
+                    const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
+                    if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
+                    ++beam_size;
+                    ++st_push;
+                }
+            } else {
                 uint32_t m = new_mask;
                 while (m) {
                     const int i = __ffs((int)m) - 1;
@@ -486,6 +578,11 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                         }
                     }
                 }
+                // the serial state lives on lane 0: make it wave-uniform again
+                beam_size = bcast_u32(beam_size);
+                nn_size = bcast_u32(nn_size);
+                gamma_q = bcast_f32(gamma_q);
+                st_push = bcast_u32(st_push);
             }
             CPH_TICK(5);
             pf_sink ^= pf;  // consumed last: the prefetch never stalls the expansion itself

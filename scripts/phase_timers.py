@@ -1,0 +1,53 @@
+"""Per-phase cycle counts of the search kernel (a -DCPH_PHASE_TIMERS build, loaded through
+CPH_LIB_PATH).  Build the instrumented library first, here or on the box:
+    python scripts/phase_timers.py --build
+then on the GPU box:  python scripts/phase_timers.py [--index /tmp/cph_bench/bench_n1000000_b4.idx]
+The library prints one "[phase cycles]" line per search to stderr."""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "build", "libcph_timers.so")
+
+
+def build(extra):
+    sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+    from cphnsw_mi355x import build as b
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [b._hipcc()] + b.FLAGS + ["-DCPH_PHASE_TIMERS"] + extra + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", LIB, "-lpthread"]
+    subprocess.check_call(cmd)
+    print(LIB)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--flag", action="append", default=[])
+    ap.add_argument("--index", default="/tmp/cph_bench/bench_n1000000_b4.idx")
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=10)
+    args = ap.parse_args()
+    if args.build:
+        return build(args.flag)
+    os.environ["CPH_LIB_PATH"] = LIB
+    sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from cphnsw_mi355x import CPIndex
+    if not os.path.exists(args.index):
+        raise SystemExit(f"{args.index} missing: run bench.py once to build it")
+    _, Q = bench.make_data(1000000, args.nq, need_base=False)
+    idx = CPIndex(dim=128, bits=4)
+    idx.load(args.index)
+    q = torch.from_numpy(Q).cuda()
+    for _ in range(3):
+        idx.search_batch_device(q, args.k)
+    torch.cuda.synchronize()
+    print(idx.last_search_stats())
+
+
+if __name__ == "__main__":
+    main()
