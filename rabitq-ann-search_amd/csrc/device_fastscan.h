@@ -317,6 +317,13 @@ __device__ __forceinline__ float chain_dot(const float* q_lds, int j, const floa
     for (int i = 0; i < N; ++i) c = __fmaf_rn(q_lds[j + 8 * i], r[i], c);
     return c;
 }
+// the same chain with both operands in LDS (v staged there by an LDS-DMA load)
+template <int N>
+__device__ __forceinline__ float chain_dot_lds(const float* q_lds, const float* v_lds, int j, float c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) c = __fmaf_rn(q_lds[j + 8 * i], v_lds[j + 8 * i], c);
+    return c;
+}
 template <int N>
 __device__ __forceinline__ float chain_l2(const float* q_lds, int j, const float (&r)[N], float c) {
 #pragma unroll

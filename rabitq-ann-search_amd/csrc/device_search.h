@@ -247,10 +247,28 @@ __device__ __forceinline__ float bcast_f32(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 }
 
-// LDS carve-up (bytes): qm[PW*16] | qv[D*4] | nn[k*8] | est[128] lower[128] exact[128]
-// ids[128] list[32+pad] | slack[128] | beam top levels (kBeamLds+1) x 16
+// LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512] (popped vertex's vector, LDS-DMA target) |
+// pf[256] (prefetch sink) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// beam top levels (kBeamLds+1) x 16
+constexpr uint32_t kLdsFixed = 512 + 256 + 128 + 64 + 128 + 16;
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
-    return (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8 + 4 * 128 + 64 + 128 + 16 + 16 * (kBeamLds + 1) + 16;
+    return (size_t)PW * 16 + (size_t)D * 4 + kLdsFixed + (((size_t)k * 8 + 15) & ~(size_t)15) + 16 * (kBeamLds + 1);
+}
+
+// LDS-DMA loads (global -> LDS, no VGPR destination), written as inline assembly on purpose: hipcc
+// waits vmcnt(0) at every later load once it has issued one itself, which would serialise the
+// neighbour-id wait behind the whole block.  The compiler therefore does not know about these
+// loads; loads retire in order, so its own counted waits stay correct (merely conservative),
+// and the one place that reads a DMA target waits explicitly.  LDS destination = M0 + lane * size.
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void*)p);
+}
+__device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_off) : "memory");
 }
 
 template <int BW, int SD>
@@ -267,18 +285,19 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
     const uint32_t k = a.k;
     uint4* qm = reinterpret_cast<uint4*>(smem);
     float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
-    Result* nn = reinterpret_cast<Result*>(smem + (size_t)PW * 16 + (size_t)D * 4);
-    float* s_est = reinterpret_cast<float*>(smem + (size_t)PW * 16 + (size_t)D * 4 + (size_t)k * 8);
-    float* s_lower = s_est + 32;
-    float* s_exact = s_lower + 32;
-    uint32_t* s_ids = reinterpret_cast<uint32_t*>(s_exact + 32);
-    uint8_t* s_list = reinterpret_cast<uint8_t*>(s_ids + 32);
-    float* s_slack = reinterpret_cast<float*>(s_list + 64);
-    double* s_ratio = reinterpret_cast<double*>(s_slack + 32);   // [2], 8-B aligned (offsets are multiples of 16)
+    unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
+    float* s_vec = reinterpret_cast<float*>(fixed);
+    unsigned char* s_pf = fixed + 512;
+    float* s_exact = reinterpret_cast<float*>(fixed + 768);
+    uint8_t* s_list = fixed + 896;
+    float* s_slack = reinterpret_cast<float*>(fixed + 960);
+    double* s_ratio = reinterpret_cast<double*>(fixed + 1088);   // [2]
+    Result* nn = reinterpret_cast<Result*>(fixed + kLdsFixed);
     // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
-    const uint32_t beam_off = (uint32_t)((PW * 16 + D * 4 + k * 8 + 4 * 128 + 64 + 128 + 16 + 15) & ~15u);
+    const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
     lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
 
+    const uint32_t vec_off = lds_offset(s_vec), pf_off = lds_offset(s_pf);
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
@@ -325,7 +344,6 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         int slack_batch = 0;
         bool overflow = false;
         uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
-        uint32_t pf_sink = 0;
 #ifdef CPH_PHASE_TIMERS
         unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tlast = clock64();
@@ -386,14 +404,20 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             // ---- neighbour ids first: the estimated-set probe (:227) is a dependent round
             // trip, so it is issued before the arithmetic on the block ----------------------
             const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
+            const float* vrow = a.raw + (size_t)cur_id * D;
+            // The popped vertex's own vector goes straight to LDS (LDS-DMA, 16 B per lane, one
+            // instruction for the 512 B; the strided per-chain reads then come from LDS).  It is
+            // issued FIRST: loads retire in order, so the wait for the neighbour ids below also
+            // covers it.
+            if constexpr (SD == 128) {
+                if (lane < 32) lds_dma16(vrow + 4 * lane, vec_off);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const uint32_t nid = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
             bl.issue(blk, a.L, lane);
-            const float* vrow = a.raw + (size_t)cur_id * D;
             const float cur_norm = a.norm_sq[cur_id];
-            float vr[16];
-            if constexpr (SD == 128) chain_load<16>(vrow, lane & 7, vr);
             // keep the uses of `nid` behind the loads above: the wait for the ids must not
             // serialise the block/vector loads behind it
             __builtin_amdgcn_sched_barrier(0);
@@ -402,28 +426,21 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
             if (active) old_bits = atomicOr(&bm[nid >> 5], my_bit);
+            // the vector DMA is the oldest load in flight: "at most one still outstanding" (the
+            // probe just issued, or the norm) means it has landed in LDS
+            if constexpr (SD == 128) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
             float exact_dist;
             {
                 float dot;
-                if constexpr (SD == 128) dot = group_reduce8(chain_dot<16>(qv, lane & 7, vr, 0.0f));
+                if constexpr (SD == 128) dot = group_reduce8(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f));
                 else dot = group_dot8(qv, vrow, D, lane & 7);
                 exact_dist = exact_from_dot(qnorm, cur_norm, dot);
             }
             LaneEst v;
             bl.reduce(blk, a.L, qm, lane, v);
-            // warm the caches for the likely next expansion (the reference prefetches
-            // beam.top() too, :124-128): one dword per 64 B line of its block and vector
-            uint32_t pf = 0;
-            {
-                const uint32_t off = (uint32_t)lane * 64u;
-                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
-                if (off < a.L.stride) pf = *reinterpret_cast<const volatile uint32_t*>(nblk + off);
-                if (off < D * 4u)
-                    pf ^= *reinterpret_cast<const volatile uint32_t*>(
-                        reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D) + off);
-            }
             st_exact++;
             st_exp++;
             if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
@@ -473,6 +490,20 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 }
             }
             const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
+            // warm the caches for the likely next expansion (the reference prefetches beam.top()
+            // too, :124-128): one dword per 64 B line of its block (lanes 0..) and of its vector
+            // (the lanes after them), as one LDS-DMA into a sink that is never read -- nothing
+            // ever waits for it.  Issued here, after the last wait of this expansion on a load.
+            {
+                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
+                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
+                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
+                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
+                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
+                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
+                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
+                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
+            }
             const bool warmup = nn_sz < k;  // (:210)
             bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
             const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
@@ -585,9 +616,10 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 st_push = bcast_u32(st_push);
             }
             CPH_TICK(5);
-            pf_sink ^= pf;  // consumed last: the prefetch never stalls the expansion itself
             log_count += n_new;
-            __syncthreads();
+            // one wave per workgroup: LDS accesses of a wave execute in program order, so only the
+            // compiler needs a fence here -- an s_barrier would also drain the prefetch (vmcnt)
+            __builtin_amdgcn_wave_barrier();
             CPH_TICK(6);
         }
 
@@ -614,7 +646,6 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             atomicAdd(&a.stats[2], (unsigned long long)st_new);
             atomicAdd(&a.stats[3], (unsigned long long)st_push);
             atomicAdd(&a.stats[4], (unsigned long long)st_skip);
-            if (pf_sink == 0x9E3779B9u) atomicAdd(&a.stats[7], 1ull);  // keeps the prefetch loads alive
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);
 #endif

@@ -28,10 +28,12 @@ def main():
     ap.add_argument("--index", default="/tmp/cph_bench/bench_n1000000_b4.idx")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--product", action="store_true", help="run the shipped library (no timers), e.g. under rocprofv3 --pmc")
     args = ap.parse_args()
     if args.build:
         return build(args.flag)
-    os.environ["CPH_LIB_PATH"] = LIB
+    if not args.product:
+        os.environ["CPH_LIB_PATH"] = LIB
     sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
     sys.path.insert(0, ROOT)
     import torch
