@@ -107,6 +107,8 @@ int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
  * [3]=beam pushes, [4]=stage-2 skipped batches, [5]=queries re-run after overflow,
  * [6]=kernel time of the last search in microseconds (HIP events), [7]=reserved. */
 int cph_last_search_stats(cph_index* h, uint64_t out[8]);
+/* Vertices expanded by each query of the last batch (its first pass); n = that batch's size. */
+int cph_last_query_expansions(cph_index* index, uint32_t* out, uint64_t n);
 
 /* ---- kernel-level hooks ------------------------------------------------------------ */
 /* Query encoder (encoder/rabitq_encoder.hpp:73-79,98-136,197-209): lut = u8[D/4][16] in

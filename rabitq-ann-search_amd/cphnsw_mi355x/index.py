@@ -126,6 +126,12 @@ class CPIndex:
                 "rerun_queries", "kernel_us", "slots_cap")
         return dict(zip(keys, [int(x) for x in out]))
 
+    def last_query_expansions(self, n):
+        """Vertices expanded by each of the n queries of the last batch."""
+        out = np.empty(int(n), np.uint32)
+        _lib.check(_lib.lib().cph_last_query_expansions(self._h, out.ctypes.data, int(n)))
+        return out
+
     def get_vectors(self, first=0, count=None):
         """Stored vectors of internal ids [first, first+count) as float32 (count, dim)."""
         if count is None:

@@ -159,7 +159,10 @@ struct cph_index {
     DevBuf<QueryHeader> d_qhdr;
     DevBuf<int64_t> d_ids;
     DevBuf<float> d_dist;
-    DevBuf<uint32_t> d_count, d_status, d_todo;
+    DevBuf<uint32_t> d_count, d_status, d_todo, d_order;
+    DevBuf<float> d_entry_dist;
+    bool order_queries = true;   // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
+    std::vector<uint32_t> last_expansions;   // per query of the last batch (first pass)
     DevBuf<uint32_t> d_counter;
     DevBuf<unsigned long long> d_stats;
     // per-slot scratch
@@ -262,6 +265,8 @@ void stage_queries(cph_index* h, const float* d_raw_q, uint64_t nq, hipStream_t 
     h->d_queries.alloc(nq * D);
     h->d_qmasks.alloc(nq * PW);
     h->d_qhdr.alloc(nq);
+    h->d_entry_dist.alloc(nq);
+    h->d_order.alloc(nq);
     EncodeArgs a{};
     a.queries_raw = d_raw_q;
     a.nq = (uint32_t)nq;
@@ -279,6 +284,7 @@ void stage_queries(cph_index* h, const float* d_raw_q, uint64_t nq, hipStream_t 
     a.queries_padded = h->d_queries.p;
     a.qmasks = h->d_qmasks.p;
     a.qhdr = h->d_qhdr.p;
+    a.entry_dist = h->d_entry_dist.p;
     if (hi.entry == kInvalidNode || hi.entry >= hi.n)
         throw std::runtime_error("Search failed: invalid entry point after finalize.");
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)h->num_cus * 32);
@@ -368,8 +374,15 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         slots = std::min(slots, h->scratch_slots);
     }
     if (!h->ev0) { HIP_CHECK(hipEventCreate(&h->ev0)); HIP_CHECK(hipEventCreate(&h->ev1)); }
+    // closest-entry-first launch order (device_encode.h) when the batch outnumbers the slots
+    const uint32_t* d_order = nullptr;
+    if (nq > slots && h->dev_max_level > 0 && h->order_queries) {
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, h->d_entry_dist.p, nq, h->d_order.p);
+        HIP_CHECK(hipGetLastError());
+        d_order = h->d_order.p;
+    }
     HIP_CHECK(hipEventRecord(h->ev0, st));
-    launch_search(h, nq, k, d_ids, d_dist, nullptr, slots, cap, st);
+    launch_search(h, nq, k, d_ids, d_dist, d_order, slots, cap, st);
     HIP_CHECK(hipEventRecord(h->ev1, st));
     // overflow check needs the statuses
     std::vector<uint32_t> status(nq);
@@ -377,9 +390,11 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0.0f;
     HIP_CHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_expansions.resize(nq);
+    for (uint32_t i = 0; i < nq; ++i) h->last_expansions[i] = status[i] >> 8;
     std::vector<uint32_t> todo;
     for (uint32_t i = 0; i < nq; ++i)
-        if (status[i] != kStatusOk) todo.push_back(i);
+        if ((status[i] & 0xFFu) != kStatusOk) todo.push_back(i);
     if (!todo.empty()) {
         // exact re-run of the overflowed queries with full-capacity scratch
         const uint64_t full = n + 1;
@@ -455,6 +470,7 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("CPH_SEARCH_KERNEL")) { int v = atoi(e); h->kernel_variant = (v == 2 || v == 4) ? v : 1; }
+        if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
         if (h->kernel_variant == 4) h->waves_per_cu = 4 * CPH_SEARCH4_WAVES_PER_SIMD;
         if (h->kernel_variant == 2) h->waves_per_cu = 4 * CPH_SEARCH2_WAVES_PER_SIMD;
         if (const char* e = getenv("CPH_WAVES_PER_CU")) h->waves_per_cu = (uint32_t)std::max(1, atoi(e));
@@ -582,6 +598,15 @@ int cph_last_search_stats(cph_index* h, uint64_t out[8]) {
     return guarded([&] {
         std::lock_guard<std::mutex> lk(h->mu);
         for (int i = 0; i < 8; ++i) out[i] = h->last_stats[i];
+    });
+}
+
+int cph_last_query_expansions(cph_index* h, uint32_t* out, uint64_t n) {
+    return guarded([&] {
+        if (!h || !out) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (n != h->last_expansions.size()) throw InvalidArg("n must equal the size of the last batch");
+        std::memcpy(out, h->last_expansions.data(), n * sizeof(uint32_t));
     });
 }
 

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         }
         if (lane == 0) {
             a.out_count[qi] = nn_final;
-            a.status[qi] = overflow ? kStatusOverflow : kStatusOk;
+            // bits 0..7: QueryStatus; bits 8..31: vertices expanded (per-query work, for load analysis)
+            a.status[qi] = (overflow ? kStatusOverflow : kStatusOk) | (st_exp << 8);
             atomicAdd(&a.stats[0], (unsigned long long)st_exp);
             atomicAdd(&a.stats[1], (unsigned long long)st_exact);
             atomicAdd(&a.stats[2], (unsigned long long)st_new);

@@ -12,28 +12,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "build", "libcph_timers.so")
 
 
-def build(extra):
+def build(extra, timers=True, out=LIB):
     sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
     from cphnsw_mi355x import build as b
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [b._hipcc()] + b.FLAGS + ["-DCPH_PHASE_TIMERS"] + extra + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", LIB, "-lpthread"]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [b._hipcc()] + b.FLAGS + (["-DCPH_PHASE_TIMERS"] if timers else []) + extra + [os.path.join(b.CSRC, s) for s in b.SOURCES] + ["-o", out, "-lpthread"]
     subprocess.check_call(cmd)
-    print(LIB)
+    print(out)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--flag", action="append", default=[])
+    ap.add_argument("--no-timers", action="store_true")
+    ap.add_argument("--lib", default=LIB, help="library to build / load")
+    ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--index", default="/tmp/cph_bench/bench_n1000000_b4.idx")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--product", action="store_true", help="run the shipped library (no timers), e.g. under rocprofv3 --pmc")
     args = ap.parse_args()
     if args.build:
-        return build(args.flag)
+        return build(args.flag, not args.no_timers, os.path.abspath(args.lib))
     if not args.product:
-        os.environ["CPH_LIB_PATH"] = LIB
+        os.environ["CPH_LIB_PATH"] = os.path.abspath(args.lib)
     sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
     sys.path.insert(0, ROOT)
     import torch
@@ -45,10 +48,12 @@ def main():
     idx = CPIndex(dim=128, bits=4)
     idx.load(args.index)
     q = torch.from_numpy(Q).cuda()
-    for _ in range(3):
+    best = 1e9
+    for _ in range(args.reps):
         idx.search_batch_device(q, args.k)
-    torch.cuda.synchronize()
-    print(idx.last_search_stats())
+        torch.cuda.synchronize()
+        best = min(best, idx.last_search_stats()["kernel_us"])
+    print("product" if args.product else os.path.basename(args.lib), "nq", args.nq, "best kernel_us", best, idx.last_search_stats())
 
 
 if __name__ == "__main__":
