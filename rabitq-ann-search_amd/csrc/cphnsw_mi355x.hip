@@ -159,11 +159,11 @@ struct cph_index {
     DevBuf<QueryHeader> d_qhdr;
     DevBuf<int64_t> d_ids;
     DevBuf<float> d_dist;
-    DevBuf<uint32_t> d_count, d_status, d_todo, d_order;
+    DevBuf<uint32_t> d_count, d_status, d_todo, d_order, d_row_of;
     DevBuf<float> d_entry_dist;
     bool order_queries = true;   // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
-    std::vector<uint32_t> last_expansions;   // per query of the last batch (first pass)
-    DevBuf<uint32_t> d_counter;
+    uint32_t last_nq = 0;                    // size of the last batch (d_status holds its per-query words)
+    unsigned long long* pin_stats = nullptr; // pinned host copy of the statistics block
     DevBuf<unsigned long long> d_stats;
     // per-slot scratch
     DevBuf<uint32_t> d_bitmaps, d_logids;
@@ -238,10 +238,25 @@ void upload_index(cph_index* h) {
     h->d_upper.alloc(flat.size() + 1);
     if (!flat.empty())
         HIP_CHECK(hipMemcpy(h->d_upper.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
-    for (int l = 0; l < kMaxUpperLayers; ++l) h->layers[l] = UpperLayerDev{nullptr, nullptr, nullptr, 0};
-    for (int l = 0; l < nl; ++l)
+    for (int l = 0; l < kMaxUpperLayers; ++l) h->layers[l] = UpperLayerDev{nullptr, nullptr, nullptr, nullptr, 0};
+    // dense vertex -> row maps for the layers where a binary search would be a long chain of
+    // dependent loads (4 B x n each)
+    int mapped = 0;
+    for (int l = 0; l < nl; ++l) mapped += hi.upper[l].size() > 16 ? 1 : 0;
+    h->d_row_of.alloc((size_t)mapped * n + 1);
+    std::vector<uint32_t> row_of;
+    for (int l = 0, m = 0; l < nl; ++l) {
+        const uint32_t* dmap = nullptr;
+        if (hi.upper[l].size() > 16) {
+            row_of.assign(n, kInvalidNode);
+            for (size_t r = 0; r < hi.upper[l].size(); ++r) row_of[hi.upper[l][r].node] = (uint32_t)r;
+            HIP_CHECK(hipMemcpy(h->d_row_of.p + (size_t)m * n, row_of.data(), n * 4, hipMemcpyHostToDevice));
+            dmap = h->d_row_of.p + (size_t)m * n;
+            ++m;
+        }
         h->layers[l] = UpperLayerDev{h->d_upper.p + off_nodes[l], h->d_upper.p + off_offs[l],
-                                     h->d_upper.p + off_nbrs[l], (uint32_t)hi.upper[l].size()};
+                                     h->d_upper.p + off_nbrs[l], dmap, (uint32_t)hi.upper[l].size()};
+    }
     h->scratch_slots = 0;
     h->scratch_cap = 0;
 }
@@ -300,7 +315,8 @@ const float* upload_queries(cph_index* h, const float* queries, uint64_t nq, hip
 }
 
 void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                   const uint32_t* d_todo, uint32_t slots, uint64_t cap, hipStream_t st) {
+                   const uint32_t* d_todo, uint32_t slots, uint64_t cap, hipStream_t st,
+                   bool reset_counter) {
     SearchArgs a{};
     a.blocks = h->d_blocks.p;
     a.raw = h->d_raw.p;
@@ -315,7 +331,8 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.nq = nq;
     a.k = k;
     a.sc = h->sc;
-    a.counter = h->d_counter.p;
+    // the work-queue counter sits right behind the 16 statistics words: one memset clears both
+    a.counter = reinterpret_cast<uint32_t*>(h->d_stats.p + 16);
     a.cap = cap;
     a.bm_words = (h->host.n + 31) / 32;
     a.bitmaps = h->d_bitmaps.p;
@@ -326,7 +343,7 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.out_count = h->d_count.p;
     a.status = h->d_status.p;
     a.stats = h->d_stats.p;
-    HIP_CHECK(hipMemsetAsync(h->d_counter.p, 0, 4, st));
+    if (reset_counter) HIP_CHECK(hipMemsetAsync(h->d_stats.p + 16, 0, 8, st));
     if (h->kernel_variant == 4 && k <= kRegNn) {
         const size_t lds = search4_lds_bytes(h->L.D, h->L.PW);
         CPH_LAUNCH(search_kernel4, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
@@ -347,9 +364,9 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     const uint64_t n = h->host.n;
     h->d_count.alloc(nq);
     h->d_status.alloc(nq);
-    h->d_counter.alloc(1);
-    h->d_stats.alloc(16);
-    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 128, st));
+    h->d_stats.alloc(17);
+    if (!h->pin_stats) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->pin_stats), 128, hipHostMallocDefault));
+    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 136, st));
     // resident query slots: one wave each
     const uint32_t qpw = h->kernel_variant == 2 ? 2u : 1u;   // query slots per wave
     uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * h->waves_per_cu * qpw;
@@ -359,12 +376,12 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     uint32_t slots = std::min<uint32_t>(nq, (nq + rounds - 1) / rounds);
     slots = (slots + qpw - 1) / qpw * qpw;
     size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
     uint64_t cap = h->want_cap ? h->want_cap : std::min<uint64_t>(n + 1, 1u << 18);
     cap = std::max<uint64_t>(64, std::min<uint64_t>(cap, n + 1));
     if (!(h->scratch_slots >= slots && h->scratch_cap == cap)) {
         // budget: at most 60% of what is free (plus what we already hold)
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
         while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots = slots / 2 / qpw * qpw;
@@ -382,19 +399,23 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         d_order = h->d_order.p;
     }
     HIP_CHECK(hipEventRecord(h->ev0, st));
-    launch_search(h, nq, k, d_ids, d_dist, d_order, slots, cap, st);
+    launch_search(h, nq, k, d_ids, d_dist, d_order, slots, cap, st, false);
     HIP_CHECK(hipEventRecord(h->ev1, st));
-    // overflow check needs the statuses
-    std::vector<uint32_t> status(nq);
-    HIP_CHECK(hipMemcpyAsync(status.data(), h->d_status.p, nq * 4, hipMemcpyDeviceToHost, st));
+    // the statistics block (pinned host copy) says whether any query overflowed its scratch
+    HIP_CHECK(hipMemcpyAsync(h->pin_stats, h->d_stats.p, 128, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0.0f;
     HIP_CHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_expansions.resize(nq);
-    for (uint32_t i = 0; i < nq; ++i) h->last_expansions[i] = status[i] >> 8;
+    unsigned long long stats[16];
+    std::memcpy(stats, h->pin_stats, 128);
+    h->last_nq = nq;
     std::vector<uint32_t> todo;
-    for (uint32_t i = 0; i < nq; ++i)
-        if ((status[i] & 0xFFu) != kStatusOk) todo.push_back(i);
+    if (stats[5] != 0) {
+        std::vector<uint32_t> status(nq);
+        HIP_CHECK(hipMemcpy(status.data(), h->d_status.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < nq; ++i)
+            if ((status[i] & 0xFFu) != kStatusOk) todo.push_back(i);
+    }
     if (!todo.empty()) {
         // exact re-run of the overflowed queries with full-capacity scratch
         const uint64_t full = n + 1;
@@ -410,15 +431,14 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
         h->d_todo.alloc(todo.size());
         HIP_CHECK(hipMemcpyAsync(h->d_todo.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipEventRecord(h->ev0, st));
-        launch_search(h, (uint32_t)todo.size(), k, d_ids, d_dist, h->d_todo.p, s2, full, st);
+        launch_search(h, (uint32_t)todo.size(), k, d_ids, d_dist, h->d_todo.p, s2, full, st, true);
         HIP_CHECK(hipEventRecord(h->ev1, st));
         HIP_CHECK(hipStreamSynchronize(st));
         float ms2 = 0.0f;
         HIP_CHECK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
         ms += ms2;
     }
-    unsigned long long stats[16];
-    HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 128, hipMemcpyDeviceToHost));
+    if (!todo.empty()) HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 128, hipMemcpyDeviceToHost));
 #ifdef CPH_PHASE_TIMERS
     fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
             stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15]);
@@ -484,6 +504,7 @@ int cph_destroy(cph_index* h) {
         (void)hipSetDevice(h->device);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->pin_stats) (void)hipHostFree(h->pin_stats);
         delete h;
     });
 }
@@ -605,8 +626,10 @@ int cph_last_query_expansions(cph_index* h, uint32_t* out, uint64_t n) {
     return guarded([&] {
         if (!h || !out) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
-        if (n != h->last_expansions.size()) throw InvalidArg("n must equal the size of the last batch");
-        std::memcpy(out, h->last_expansions.data(), n * sizeof(uint32_t));
+        if (n != h->last_nq) throw InvalidArg("n must equal the size of the last batch");
+        h->use_device();
+        HIP_CHECK(hipMemcpy(out, h->d_status.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) out[i] >>= 8;
     });
 }
 

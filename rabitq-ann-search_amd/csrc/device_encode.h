@@ -20,6 +20,7 @@ struct UpperLayerDev {       // CSR of one upper layer, nodes sorted ascending (
     const uint32_t* nodes;   // [n_nodes]
     const uint32_t* offsets; // [n_nodes + 1]
     const uint32_t* nbrs;
+    const uint32_t* row_of;  // [n] vertex -> row in `nodes` (kInvalidNode if absent), or null: binary search
     uint32_t n_nodes;
 };
 
@@ -143,11 +144,17 @@ __global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
                     improved = false;
                     // find_edge: lower_bound over the sorted node list (uniform across lanes)
                     uint32_t lo = 0, hi = Ly.n_nodes;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (Ly.nodes[mid] < best_id) lo = mid + 1; else hi = mid;
+                    if (Ly.row_of) {
+                        // dense vertex -> row map: one load instead of log2(n_nodes) dependent ones
+                        lo = Ly.row_of[best_id];
+                        if (lo == kInvalidNode) break;
+                    } else {
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (Ly.nodes[mid] < best_id) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo >= Ly.n_nodes || Ly.nodes[lo] != best_id) break;
                     }
-                    if (lo >= Ly.n_nodes || Ly.nodes[lo] != best_id) break;
                     const uint32_t beg = Ly.offsets[lo], end = Ly.offsets[lo + 1];
                     // neighbours in stored order; strict improvement => the first minimum wins
                     float cand = 3.402823466e+38f;
