@@ -547,18 +547,39 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 const float dabs0 = gamma_q * worst0;
                 const bool p = is_new && !(lower >= worst0) && est < dabs0;
                 uint32_t pm = (uint32_t)(__ballot(p) & 0xFFFFFFFFull);
-                while (pm) {
-                    const int i = __ffs((int)pm) - 1;
-                    pm &= pm - 1;
-                    const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
-                    const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
-                    const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
-                    if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
-                    ++beam_size;
-                    ++st_push;
+                // std::push_heap of each in neighbour order.  Usual case: every new entry is no
+                // better than the parent of the leaf it lands on, so nothing moves and the pushes
+                // are independent appends -- each lane checks its own parent and writes its own leaf.
+                const uint32_t np = __popc(pm);
+                bool appended = false;
+                if (np != 0 && np <= beam_size + 1 && beam_size + np <= kBeamLds) {
+                    const uint32_t pos = beam_size + __popc(pm & ((1u << li) - 1u));
+                    bool stay = true;
+                    if (p && pos > 0) stay = !(heap.lds_key((pos - 1) >> 1) > est);
+                    if (__all(stay)) {
+                        if (p) heap.lds_put(pos, make_uint4(__float_as_uint(est), __float_as_uint(lower), nid, 0u));
+                        beam_size += np;
+                        st_push += np;
+                        appended = true;
+                    }
+                }
+                if (!appended) {
+                    while (pm) {
+                        const int i = __ffs((int)pm) - 1;
+                        pm &= pm - 1;
+                        const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
+                        const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
+                        const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
+                        if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
+                        ++beam_size;
+                        ++st_push;
+                    }
                 }
             } else {
-                uint32_t m = new_mask;
+                // past the warm-up the threshold only falls: a lower bound that fails it at loop
+                // entry fails it at its turn too (:241), so those neighbours are dropped here
+                uint32_t m = warmup ? new_mask
+                                    : new_mask & (uint32_t)(__ballot(!(lower >= worst0)) & 0xFFFFFFFFull);
                 while (m) {
                     const int i = __ffs((int)m) - 1;
                     m &= m - 1;

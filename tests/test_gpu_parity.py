@@ -185,6 +185,27 @@ def test_capacity_overflow_rerun_is_exact(cph, gold):
     assert np.array_equal(ids, gold["S/g128/b2/plain/k10/ids"]) and _beq(d, gold["S/g128/b2/plain/k10/d"])
 
 
+@pytest.mark.parametrize("name,bits", [("g128", 4), ("sift96", 4), ("g16", 1)])
+def test_launch_order_and_per_query_work(cph, oracle, gold, name, bits):
+    """More queries than resident slots: the closest-entry-first launch order changes nothing in
+    the results, and the per-query expansion counts equal the oracle's counters."""
+    ix = _load(cph, name, bits)
+    ix.set_search_params(slots=4, beam_capacity=0)
+    Q = gold[f"Q/{name}"]
+    ids, d = ix.search_batch(Q, 10)
+    assert np.array_equal(ids, gold[f"S/{name}/b{bits}/plain/k10/ids"])
+    assert _beq(d, gold[f"S/{name}/b{bits}/plain/k10/d"])
+    st = ix.last_search_stats()
+    assert st["rerun_queries"] == 0 and (st["slots_cap"] >> 32) == 4
+    work = ix.last_query_expansions(len(Q))
+    assert int(work.sum()) == st["expansions"]
+    oi = oracle.load(fixture_path(name, bits))
+    _, _, _, ctr = oi.search_batch(Q, 10, counters=True)
+    assert np.array_equal(work.astype(np.uint64), ctr[:, 0])
+    with pytest.raises(ValueError):
+        ix.last_query_expansions(len(Q) + 1)
+
+
 def test_large_index_against_oracle(cph, oracle, tmp_path):
     """Bigger graph (many thousands of expansions per query): GPU vs the oracle on an index built
     by the compiled reference when it is available on this box."""
