@@ -441,6 +441,24 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             }
             LaneEst v;
             bl.reduce(blk, a.L, qm, lane, v);
+            // warm the caches for the likely next expansion (the reference prefetches beam.top()
+            // too, :124-128): one dword per 64 B line of its block (lanes 0..) and of its vector
+            // (the lanes after them), as one LDS-DMA into a sink that is never read -- nothing
+            // waits for it on its own.  Placement: the compiler does not know about this load, and a
+            // counted wait (vmcnt(N)) is one too strict for every unknown load YOUNGER than the ones it
+            // counts -- so it goes behind the last counted wait of this expansion (the block data,
+            // just consumed) and ahead of the estimator arithmetic; only the probe's result, which is
+            // waited for with vmcnt(0) anyway, retires after it.
+            {
+                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
+                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
+                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
+                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
+                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
+                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
+                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
+                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
+            }
             st_exact++;
             st_exp++;
             if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
@@ -490,27 +508,13 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 }
             }
             const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
-            // warm the caches for the likely next expansion (the reference prefetches beam.top()
-            // too, :124-128): one dword per 64 B line of its block (lanes 0..) and of its vector
-            // (the lanes after them), as one LDS-DMA into a sink that is never read -- nothing
-            // ever waits for it.  Issued here, after the last wait of this expansion on a load.
-            {
-                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
-                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
-                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
-                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
-                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
-                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
-                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
-                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
-            }
             const bool warmup = nn_sz < k;  // (:210)
             bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
             const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
 
             // log new ids (discovery order = neighbour order)
             const uint32_t n_new = __popc(new_mask);
-            const uint32_t my_rank = __popc(new_mask & ((1u << li) - 1u));
+            const uint32_t my_rank = __builtin_amdgcn_mbcnt_lo(new_mask, 0u);   // set bits below this lane (lanes < 32)
             if (log_count + n_new > a.cap) { overflow = true; break; }
             if (is_new) logi[log_count + my_rank] = nid;
             st_new += n_new;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
 
             // ---- speculative exact L2 of the candidates, 8 per pass (rare: ~0.15 per expansion) --
             if (cand_mask) {
-                if (cand) s_list[__popc(cand_mask & ((1u << li) - 1u))] = (uint8_t)lane;
+                if (cand) s_list[__builtin_amdgcn_mbcnt_lo(cand_mask, 0u)] = (uint8_t)lane;
                 __syncthreads();
                 const uint32_t n_cand = __popc(cand_mask);
                 const int g = lane >> 3;
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 const uint32_t np = __popc(pm);
                 bool appended = false;
                 if (np != 0 && np <= beam_size + 1 && beam_size + np <= kBeamLds) {
-                    const uint32_t pos = beam_size + __popc(pm & ((1u << li) - 1u));
+                    const uint32_t pos = beam_size + __builtin_amdgcn_mbcnt_lo(pm, 0u);
                     bool stay = true;
                     if (p && pos > 0) stay = !(heap.lds_key((pos - 1) >> 1) > est);
                     if (__all(stay)) {
