@@ -157,6 +157,16 @@ struct BlockLoads {
         aux = reinterpret_cast<const uint4*>(blk + L.aux_off)[lane & 31];
     }
 
+    // Makes the compiler retire (wait for) the loads of issue() at this point of the program.
+    __device__ __forceinline__ void retire() {
+        if constexpr (kStatic) {
+#pragma unroll
+            for (int k = 0; k < kCPL; ++k)
+                asm volatile("" : "+v"(c[k].x), "+v"(c[k].y), "+v"(c[k].z), "+v"(c[k].w));
+        }
+        asm volatile("" : "+v"(aux.x), "+v"(aux.y), "+v"(aux.z), "+v"(aux.w));
+    }
+
     __device__ __forceinline__ void reduce(const uint8_t* __restrict__ blk, const DevLayout& L,
                                            const uint4* qm, int lane, LaneEst& o) {
         if constexpr (kStatic) {

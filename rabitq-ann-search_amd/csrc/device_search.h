@@ -405,6 +405,11 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             // trip, so it is issued before the arithmetic on the block ----------------------
             const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
             const float* vrow = a.raw + (size_t)cur_id * D;
+            // Nothing that matters is in flight here (the previous expansion's prefetch is thousands
+            // of cycles old, its marking atomics return nothing).  Saying so with a wait the compiler
+            // can see keeps it from protecting registers it believes some path around the loop left
+            // a load pending on -- such a wait, between the loads below, would be a real one.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             // The popped vertex's own vector goes straight to LDS (LDS-DMA, 16 B per lane, one
             // instruction for the 512 B; the strided per-chain reads then come from LDS).  It is
             // issued FIRST: loads retire in order, so the wait for the neighbour ids below also
@@ -413,42 +418,40 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                 if (lane < 32) lds_dma16(vrow + 4 * lane, vec_off);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const uint32_t nid = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
+            const float norm_ld = a.norm_sq[cur_id];
+            const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
             bl.issue(blk, a.L, lane);
-            const float cur_norm = a.norm_sq[cur_id];
-            // keep the uses of `nid` behind the loads above: the wait for the ids must not
-            // serialise the block/vector loads behind it
             __builtin_amdgcn_sched_barrier(0);
+            // All of this expansion's loads come back together (issued back to back, retired in
+            // order); they are retired HERE, before the probe goes out.  The probe is only issued when
+            // a lane has something to look up, and a load that is only maybe in flight makes every
+            // later wait of the compiler a vmcnt(0) -- the norm or the codes would then wait for the
+            // probe's round trip.  This way that round trip (and the prefetch behind it) overlaps the
+            // whole estimator arithmetic; the vector DMA is older than these loads, so it has landed.
+            uint32_t nid = nid_ld;
+            float cur_norm = norm_ld;
+            float dot_generic = 0.0f;
+            if constexpr (SD != 128) dot_generic = group_dot8(qv, vrow, D, lane & 7);   // its loads, too, go first
+            bl.retire();
+            asm volatile("" : "+v"(cur_norm), "+v"(nid));
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
             const bool active = lane < 32 && valid;
+            // The probe is a plain (device-coherent: it must not be served from this CU's L1, which
+            // the marking atomics below bypass) load of the slot's bitmap word; only the few
+            // neighbours that turn out to be new pay for a read-modify-write, and that one needs
+            // no return value.  (A test-and-set for all 32 made the L2 atomic units the bottleneck.)
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
-            if (active) old_bits = atomicOr(&bm[nid >> 5], my_bit);
-            // the vector DMA is the oldest load in flight: "at most one still outstanding" (the
-            // probe just issued, or the norm) means it has landed in LDS
-            if constexpr (SD == 128) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-
-            // ---- exact distance of the popped node; nn.push (:130-133) ----------------
-            float exact_dist;
-            {
-                float dot;
-                if constexpr (SD == 128) dot = group_reduce8(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f));
-                else dot = group_dot8(qv, vrow, D, lane & 7);
-                exact_dist = exact_from_dot(qnorm, cur_norm, dot);
-            }
-            LaneEst v;
-            bl.reduce(blk, a.L, qm, lane, v);
+            if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // warm the caches for the likely next expansion (the reference prefetches beam.top()
             // too, :124-128): one dword per 64 B line of its block (lanes 0..) and of its vector
             // (the lanes after them), as one LDS-DMA into a sink that is never read -- nothing
-            // waits for it on its own.  Placement: the compiler does not know about this load, and a
-            // counted wait (vmcnt(N)) is one too strict for every unknown load YOUNGER than the ones it
-            // counts -- so it goes behind the last counted wait of this expansion (the block data,
-            // just consumed) and ahead of the estimator arithmetic; only the probe's result, which is
-            // waited for with vmcnt(0) anyway, retires after it.
+            // waits for it on its own.  The compiler does not know about this load, and a counted wait
+            // (vmcnt(N)) is one too strict for every unknown load YOUNGER than the ones it counts: it
+            // goes right behind the probe, the only load of this expansion still to be waited for
+            // (with vmcnt(0)), so it has the whole arithmetic below as lead.
             {
                 const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
                 const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
@@ -459,6 +462,18 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                                                                 : nvec + ((uint32_t)lane - blk_lines) * 64u;
                 if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
             }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- exact distance of the popped node; nn.push (:130-133) ----------------
+            float exact_dist;
+            {
+                float dot;
+                if constexpr (SD == 128) dot = group_reduce8(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f));
+                else dot = dot_generic;
+                exact_dist = exact_from_dot(qnorm, cur_norm, dot);
+            }
+            LaneEst v;
+            bl.reduce(blk, a.L, qm, lane, v);
             st_exact++;
             st_exp++;
             if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
@@ -467,7 +482,12 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             const uint32_t nn_sz = nn_size;
             const float worst0 = bcast_f32(nn_sz ? nn[0].dist : FMAX);
             CPH_TICK(1);
-            if (!__any(active)) continue;  // n_neighbors == 0 (:137)
+            if (!__any(active)) {  // n_neighbors == 0 (:137)
+                // (retire the probe's destination register on this path too: a load left pending
+                // across the back edge costs every expansion a wait where that register is reused)
+                asm volatile("" ::"v"(old_bits));
+                continue;
+            }
 
             // slack level schedule (:141-145)
             if (a.sc.num_slack > 0) {
@@ -507,6 +527,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                     if (nj && lane > j && lane < 32 && oj == nid) is_new = false;
                 }
             }
+            if (is_new) atomicOr(&bm[nid >> 5], my_bit);   // mark (two new ids may share a word)
             const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
             const bool warmup = nn_sz < k;  // (:210)
             bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
