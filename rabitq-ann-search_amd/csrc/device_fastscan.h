@@ -50,6 +50,14 @@ __device__ __forceinline__ void acc4(uint32_t c, uint4 q, uint32_t& a0, uint32_t
 
 // Integer sums of one block.  qm = LDS, uint4 per 32-dim word: {Q0,Q1,Q2,Q3}.
 // SD = compile-time D (0 = runtime D from the layout).
+// Both halves of the wave see both values: lo = x of lane (l & 31), hi = x of lane (l | 32).
+// One v_permlane32_swap (gfx950) instead of a ds_bpermute through the LDS crossbar.
+__device__ __forceinline__ void half_pair(uint32_t x, uint32_t& lo, uint32_t& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    lo = r[0];
+    hi = r[1];
+}
+
 template <int BW, int SD>
 __device__ __forceinline__ void block_sums(const uint8_t* __restrict__ blk, const DevLayout& L,
                                            const uint4* qm, int lane, uint32_t& nbit,
@@ -80,18 +88,16 @@ __device__ __forceinline__ void block_sums(const uint8_t* __restrict__ blk, cons
             uint32_t part = 0;
 #pragma unroll
             for (int pl = 0; pl < PPH; ++pl) part += S[pl] << (BW - 1 - (h * PPH + pl));
-            uint32_t other = __shfl_xor(part, 32);
-            nbit = part + other;
-            uint32_t s0_other = __shfl_xor(S[0], 32);
+            uint32_t plo, phi, s0, s0hi;
+            half_pair(part, plo, phi);
+            nbit = plo + phi;
+            half_pair(S[0], s0, s0hi);          // plane 0 lives in the h = 0 half
             if constexpr (BW == 2) {
-                uint32_t s0 = h ? s0_other : S[0];
-                uint32_t s1 = h ? S[0] : s0_other;
                 msb = s0;
-                msb2 = 2 * s0 + s1;
+                msb2 = 2 * s0 + s0hi;           // plane 1 = S[0] of the h = 1 half
             } else {
-                uint32_t s1_other = __shfl_xor(S[1], 32);
-                uint32_t s0 = h ? s0_other : S[0];
-                uint32_t s1 = h ? s1_other : S[1];
+                uint32_t s1, s1hi;
+                half_pair(S[1], s1, s1hi);      // planes 0,1 both in the h = 0 half
                 msb = s0;
                 msb2 = 2 * s0 + s1;
             }
@@ -111,9 +117,9 @@ __device__ __forceinline__ void block_sums(const uint8_t* __restrict__ blk, cons
                     acc4(c.w, qm[w0 + 3], a0, a1, a2, a3);
                 }
             }
-            uint32_t s = a0 + 2 * a1 + 4 * a2 + 8 * a3;
-            uint32_t o = __shfl_xor(s, 32);
-            s = (NH == 2) ? s + o : (h ? o : s);
+            uint32_t s = a0 + 2 * a1 + 4 * a2 + 8 * a3, slo, shi;
+            half_pair(s, slo, shi);
+            s = (NH == 2) ? slo + shi : slo;
             nbit = msb = msb2 = s;
         }
     } else {
@@ -192,17 +198,16 @@ struct BlockLoads {
                 uint32_t part = 0;
 #pragma unroll
                 for (int pl = 0; pl < PPH; ++pl) part += S[pl] << (BW - 1 - (h * PPH + pl));
-                o.nbit = part + __shfl_xor(part, 32);
-                const uint32_t s0_other = __shfl_xor(S[0], 32);
+                uint32_t plo, phi, s0, s0hi;
+                half_pair(part, plo, phi);
+                o.nbit = plo + phi;
+                half_pair(S[0], s0, s0hi);      // plane 0 lives in the h = 0 half
                 if constexpr (BW == 2) {
-                    const uint32_t s0 = h ? s0_other : S[0];
-                    const uint32_t s1 = h ? S[0] : s0_other;
                     o.msb = s0;
-                    o.msb2 = 2 * s0 + s1;
+                    o.msb2 = 2 * s0 + s0hi;     // plane 1 = S[0] of the h = 1 half
                 } else {
-                    const uint32_t s1_other = __shfl_xor(S[1], 32);
-                    const uint32_t s0 = h ? s0_other : S[0];
-                    const uint32_t s1 = h ? s1_other : S[1];
+                    uint32_t s1, s1hi;
+                    half_pair(S[1], s1, s1hi);  // planes 0,1 both in the h = 0 half
                     o.msb = s0;
                     o.msb2 = 2 * s0 + s1;
                 }
@@ -219,9 +224,9 @@ struct BlockLoads {
                         acc4(cc.w, qm[w0 + 3], a0, a1, a2, a3);
                     }
                 }
-                uint32_t sv = a0 + 2 * a1 + 4 * a2 + 8 * a3;
-                const uint32_t ov = __shfl_xor(sv, 32);
-                sv = (kNH == 2) ? sv + ov : (h ? ov : sv);
+                uint32_t sv = a0 + 2 * a1 + 4 * a2 + 8 * a3, slo, shi;
+                half_pair(sv, slo, shi);
+                sv = (kNH == 2) ? slo + shi : slo;
                 o.nbit = o.msb = o.msb2 = sv;
             }
         } else {
@@ -314,6 +319,19 @@ __device__ __forceinline__ float group_reduce8(float c) {
     float b = a + __shfl_xor(a, 1);
     return b + __shfl_xor(b, 2);
 }
+// The same sum with DPP operands instead of LDS-crossbar shuffles (three v_add_f32_dpp).  Only
+// lanes 0..3 of each 8-lane group end up with the result (row_shl:4 feeds lanes 4..7 from the
+// next group); fp add is commutative, so the pairing ((c0+c4)+(c1+c5))+((c2+c6)+(c3+c7)) and
+// its rounding are unchanged.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group_reduce8_lo(float c) {
+    const float a = c + dpp_mov<0x104>(c);   // row_shl:4         lane j <- lane j+4
+    const float b = a + dpp_mov<0xB1>(a);    // quad_perm [1,0,3,2]  lane j <- lane j^1
+    return b + dpp_mov<0x4E>(b);             // quad_perm [2,3,0,1]  lane j <- lane j^2
+}
 
 // N chain elements of lane j: loads first (all in flight together), then the FMA chain.
 template <int N>
@@ -359,6 +377,24 @@ __device__ __forceinline__ float group_dot8(const float* q_lds, const float* __r
         for (uint32_t i = j; i < D; i += 8) c = __fmaf_rn(q_lds[i], v[i], c);
     }
     return group_reduce8(c);
+}
+
+// group_dot8 with the DPP reduction: the result is valid in lanes 0..3 of each 8-lane group only.
+// dot(q, v): q in LDS, v a global row; j = lane & 7.  128-element chunks keep 16 loads per
+// lane in flight per round trip.
+__device__ __forceinline__ float group_dot8_lo(const float* q_lds, const float* __restrict__ v,
+                                             uint32_t D, int j) {
+    float c = 0.0f;
+    if (D >= 128) {
+        for (uint32_t base = 0; base < D; base += 128) {
+            float r[16];
+            chain_load<16>(v + base, j, r);
+            c = chain_dot<16>(q_lds + base, j, r, c);
+        }
+    } else {
+        for (uint32_t i = j; i < D; i += 8) c = __fmaf_rn(q_lds[i], v[i], c);
+    }
+    return group_reduce8_lo(c);
 }
 
 // sum (q - v)^2 with the same chain structure (l2_distance_simd, core/memory.hpp:65-79).

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         {
             float c = 0.0f;
             for (uint32_t i = lane & 7; i < D; i += 8) c = __fmaf_rn(qv[i], qv[i], c);
-            qnorm = group_reduce8(c);
+            qnorm = bcast_f32(group_reduce8_lo(c));
         }
 
         // wave-uniform heap sizes (re-broadcast after every lane-0 section)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
         // entry: ep_est = exact_l2(ep); beam.push({ep_est, 0, ep}); mark estimated (:95-97)
         {
             const uint32_t ep = hd.entry;
-            float dot = group_dot8(qv, a.raw + (size_t)ep * D, D, lane & 7);
+            float dot = group_dot8_lo(qv, a.raw + (size_t)ep * D, D, lane & 7);
             float ex = exact_from_dot(qnorm, a.norm_sq[ep], dot);
             st_exact++;
             if (lane == 0) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             uint32_t nid = nid_ld;
             float cur_norm = norm_ld;
             float dot_generic = 0.0f;
-            if constexpr (SD != 128) dot_generic = group_dot8(qv, vrow, D, lane & 7);   // its loads, too, go first
+            if constexpr (SD != 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
             bl.retire();
             asm volatile("" : "+v"(cur_norm), "+v"(nid));
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             float exact_dist;
             {
                 float dot;
-                if constexpr (SD == 128) dot = group_reduce8(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f));
+                if constexpr (SD == 128) dot = bcast_f32(group_reduce8_lo(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f)));
                 else dot = dot_generic;
                 exact_dist = exact_from_dot(qnorm, cur_norm, dot);
             }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                     const uint32_t idx = have ? s_list[base + g] : 0;
                     const uint32_t cid_l = (uint32_t)__shfl((int)nid, (int)idx);
                     const uint32_t cid = have ? cid_l : cur_id;
-                    float dot = group_dot8(qv, a.raw + (size_t)cid * D, D, lane & 7);
+                    float dot = group_dot8_lo(qv, a.raw + (size_t)cid * D, D, lane & 7);
                     float ex = exact_from_dot(qnorm, a.norm_sq[cid], dot);
                     if (have && (lane & 7) == 0) s_exact[idx] = ex;
                 }
