@@ -209,22 +209,26 @@ __device__ __forceinline__ uint32_t beam_pop_wave(const Beam& h, uint32_t size, 
         if ((uint32_t)lane + 64 < nint) b1 = h.lds_key(2 * lane + 130) > h.lds_key(2 * lane + 129);
         m1 = __ballot(b1);
     }
-    uint32_t hole = 0, d = 0;
-    uint32_t my_dst = 0, my_src = 0;              // lane t moves entry p_{t+1} into p_t
-    while (hole < nint) {
+    // Walk on hp = hole + 1: taking the left child doubles it, the right child doubles it and adds 1,
+    // so after d steps hp is the binary string "1 r0 r1 .. r(d-1)" of the choices and every node on
+    // the path is a prefix of it -- p_t = (hp >> (d - t)) - 1.  The loop is scalar-only; each lane
+    // then derives its own pair of path positions with two shifts.
+    uint32_t hp = 1, d = 0;
+    while (hp - 1 < nint) {
+        const uint32_t hole = hp - 1;
         const unsigned long long m = hole < 64 ? m0 : m1;
         const uint32_t left = (uint32_t)(m >> (hole & 63)) & 1u;
-        const uint32_t child = 2 * hole + 2 - left;
-        if ((uint32_t)lane == d) { my_dst = hole; my_src = child; }
-        hole = child;
+        hp = 2 * hp + 1 - left;
         ++d;
     }
-    if ((len & 1) == 0 && hole == (len - 2) >> 1) {   // a last node with a left child only
-        const uint32_t child = 2 * hole + 1;
-        if ((uint32_t)lane == d) { my_dst = hole; my_src = child; }
-        hole = child;
+    if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
+        hp = 2 * hp;
         ++d;
     }
+    const uint32_t hole = hp - 1;                                   // p_d, where the walk ends
+    const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
+    const uint32_t my_dst = (hp >> (d - t)) - 1;                    // p_t: lane t moves entry p_{t+1} into it
+    const uint32_t my_src = (hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u))) - 1;   // p_{t+1}
     uint4 e = make_uint4(0, 0, 0, 0);
     bool c = false;                                // __push_heap: parent (now e_t) > v -> parent moves down
     if ((uint32_t)lane < d) {
@@ -372,10 +376,12 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
             // ---- pop + termination tests (lane 0) (:106-122) --------------------------
             CPH_TICK(7);
             if (beam_size == 0) break;
-            uint32_t cur_id, next_id;
+            uint32_t cur_id, next_id = 0;
             {
+                // every LDS read the pop needs first goes out together: the top, the result-heap
+                // threshold, and (inside beam_pop_wave) the re-inserted entry and the child keys
                 const uint4 topv = heap.lds(0);
-                cur_id = bcast_u32(topv.z);
+                const float worst = nn_size ? nn[0].dist : FMAX;
                 if (beam_size > 1) {
                     if (beam_size <= kBeamLds) {
                         next_id = beam_pop_wave(heap, beam_size, lane);
@@ -385,13 +391,12 @@ __global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(S
                         next_id = heap.lds(0).z;
                     }
                     next_id = bcast_u32(next_id);
-                } else {
-                    next_id = cur_id;
                 }
+                cur_id = bcast_u32(topv.z);
+                if (beam_size <= 1) next_id = cur_id;
                 --beam_size;
                 const float cur_est = __uint_as_float(topv.x);
                 const float cur_lower = __uint_as_float(topv.y);
-                const float worst = nn_size ? nn[0].dist : FMAX;
                 uint32_t verdict = 2;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
                 if (nn_size >= k && cur_est >= gamma_q * worst) verdict = 0;
                 else if (nn_size >= k && cur_lower > worst) verdict = 1;
