@@ -141,6 +141,7 @@ struct cph_index {
     SearchConsts sc{};
     uint32_t flags = 0;
     int num_cus = 256;
+    bool waves_from_env = false;
     uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident waves per CU (launch bounds of the search kernel)
     int kernel_variant = 1;            // 1 = LDS heaps, one query per wave; 2 = two queries per wave; 4 = register heaps
     // device-resident index
@@ -369,11 +370,17 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 136, st));
     // resident query slots: one wave each
     const uint32_t qpw = h->kernel_variant == 2 ? 2u : 1u;   // query slots per wave
-    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * h->waves_per_cu * qpw;
+    uint32_t wpc = h->waves_per_cu;
+    if (h->kernel_variant == 1 && !h->waves_from_env) wpc = 4 * (h->L.D == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD);
+    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc * qpw;
     // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
     // would leave 56% of the slots idle during the third round)
     const uint32_t rounds = (nq + max_slots - 1) / max_slots;
     uint32_t slots = std::min<uint32_t>(nq, (nq + rounds - 1) / rounds);
+    // ... unless the batch is launched longest-first (below): then every slot is worth having, the
+    // short queries at the end of the order fill the gaps
+    const bool ordered = h->dev_max_level > 0 && h->order_queries;
+    if (ordered) slots = std::min<uint32_t>(nq, max_slots);
     slots = (slots + qpw - 1) / qpw * qpw;
     size_t free_b = 0, total_b = 0;
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
@@ -393,7 +400,7 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     if (!h->ev0) { HIP_CHECK(hipEventCreate(&h->ev0)); HIP_CHECK(hipEventCreate(&h->ev1)); }
     // closest-entry-first launch order (device_encode.h) when the batch outnumbers the slots
     const uint32_t* d_order = nullptr;
-    if (nq > slots && h->dev_max_level > 0 && h->order_queries) {
+    if (nq > slots && ordered) {
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, h->d_entry_dist.p, nq, h->d_order.p);
         HIP_CHECK(hipGetLastError());
         d_order = h->d_order.p;
@@ -493,7 +500,7 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
         if (h->kernel_variant == 4) h->waves_per_cu = 4 * CPH_SEARCH4_WAVES_PER_SIMD;
         if (h->kernel_variant == 2) h->waves_per_cu = 4 * CPH_SEARCH2_WAVES_PER_SIMD;
-        if (const char* e = getenv("CPH_WAVES_PER_CU")) h->waves_per_cu = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("CPH_WAVES_PER_CU")) { h->waves_per_cu = (uint32_t)std::max(1, atoi(e)); h->waves_from_env = true; }
         *out = h;
     });
 }

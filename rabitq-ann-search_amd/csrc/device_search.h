@@ -276,11 +276,15 @@ __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
 }
 
 template <int BW, int SD>
-// 5 waves per SIMD (<= 96 VGPRs): measured best of {4,5,6,8} on MI355X
+// Waves per SIMD: 6 (<= 80 VGPRs) for the static D = 128 instantiations, 5 (<= 96 VGPRs) for the
+// generic ones -- measured on MI355X
 #ifndef CPH_SEARCH_WAVES_PER_SIMD
 #define CPH_SEARCH_WAVES_PER_SIMD 5
 #endif
-__global__ __launch_bounds__(64, CPH_SEARCH_WAVES_PER_SIMD) void search_kernel(SearchArgs a) {
+#ifndef CPH_SEARCH_WAVES_PER_SIMD_128
+#define CPH_SEARCH_WAVES_PER_SIMD_128 6
+#endif
+__global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD)) void search_kernel(SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int li = lane & 31;
