@@ -196,8 +196,8 @@ __device__ __forceinline__ void beam_adjust(const Beam& h, uint32_t hole, uint32
 // once (lane j <-> nodes j and j+64, one ballot each), the root-to-leaf path is then walked on
 // wave-uniform bit masks with no memory access, and the moves along the path are one parallel
 // LDS read plus one parallel write.  Two LDS round trips instead of one dependent round trip
-// per heap level.  Returns the id at the new top.
-__device__ __forceinline__ uint32_t beam_pop_wave(const Beam& h, uint32_t size, int lane) {
+// per heap level.
+__device__ __forceinline__ void beam_pop_wave(const Beam& h, uint32_t size, int lane) {
     const uint32_t len = size - 1;                // heap length once the last element is taken out
     const uint4 v = h.lds(len);                   // the value __adjust_heap re-inserts
     const uint32_t nint = (len - 1) >> 1;         // nodes j < nint have both children below len
@@ -240,8 +240,6 @@ __device__ __forceinline__ uint32_t beam_pop_wave(const Beam& h, uint32_t size, 
     if ((uint32_t)lane < fin) h.lds_put(my_dst, e);
     if (fin == d) { if (lane == 0) h.lds_put(hole, v); }
     else if ((uint32_t)lane == fin) h.lds_put(my_dst, v);
-    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
-    return fin == 0 ? v.z : e0;
 }
 
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v) {
@@ -252,7 +250,7 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512] (popped vertex's vector, LDS-DMA target) |
-// pf[256] (prefetch sink) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// (256 spare) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
 constexpr uint32_t kLdsFixed = 512 + 256 + 128 + 64 + 128 + 16;
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
@@ -270,9 +268,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
 }
 __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_off) : "memory");
 }
 
 template <int BW, int SD>
@@ -295,7 +290,6 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
     unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
     float* s_vec = reinterpret_cast<float*>(fixed);
-    unsigned char* s_pf = fixed + 512;
     float* s_exact = reinterpret_cast<float*>(fixed + 768);
     uint8_t* s_list = fixed + 896;
     float* s_slack = reinterpret_cast<float*>(fixed + 960);
@@ -305,7 +299,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
     lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
 
-    const uint32_t vec_off = lds_offset(s_vec), pf_off = lds_offset(s_pf);
+    const uint32_t vec_off = lds_offset(s_vec);
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
@@ -380,7 +374,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             // ---- pop + termination tests (lane 0) (:106-122) --------------------------
             CPH_TICK(7);
             if (beam_size == 0) break;
-            uint32_t cur_id, next_id = 0;
+            uint32_t cur_id;
             {
                 // every LDS read the pop needs first goes out together: the top, the result-heap
                 // threshold, and (inside beam_pop_wave) the re-inserted entry and the child keys
@@ -388,16 +382,13 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 const float worst = nn_size ? nn[0].dist : FMAX;
                 if (beam_size > 1) {
                     if (beam_size <= kBeamLds) {
-                        next_id = beam_pop_wave(heap, beam_size, lane);
+                        beam_pop_wave(heap, beam_size, lane);
                     } else {
                         if (lane == 0) beam_adjust(heap, 0, beam_size - 1, heap.raw(beam_size - 1));
                         __builtin_amdgcn_wave_barrier();
-                        next_id = heap.lds(0).z;
                     }
-                    next_id = bcast_u32(next_id);
                 }
                 cur_id = bcast_u32(topv.z);
-                if (beam_size <= 1) next_id = cur_id;
                 --beam_size;
                 const float cur_est = __uint_as_float(topv.x);
                 const float cur_lower = __uint_as_float(topv.y);
@@ -454,23 +445,11 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
             if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // warm the caches for the likely next expansion (the reference prefetches beam.top()
-            // too, :124-128): one dword per 64 B line of its block (lanes 0..) and of its vector
-            // (the lanes after them), as one LDS-DMA into a sink that is never read -- nothing
-            // waits for it on its own.  The compiler does not know about this load, and a counted wait
-            // (vmcnt(N)) is one too strict for every unknown load YOUNGER than the ones it counts: it
-            // goes right behind the probe, the only load of this expansion still to be waited for
-            // (with vmcnt(0)), so it has the whole arithmetic below as lead.
-            {
-                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
-                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
-                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
-                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
-                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
-                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
-                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
-                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
-            }
+            // (No software prefetch of the next vertex: the reference prefetches beam.top() at this
+            // point, :124-128, and so did this kernel -- but with thousands of queries in flight the
+            // latency is hidden anyway, and the ~40 % of predictions that a later push invalidates
+            // cost HBM bandwidth that at large batches is the scarcer resource: 22.9 -> 21.1 ms per
+            // 100k queries without it, 3.03 -> 2.85 ms per 10k.)
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
