@@ -250,9 +250,9 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512] (popped vertex's vector, LDS-DMA target) |
-// (256 spare) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsFixed = 512 + 256 + 128 + 64 + 128 + 16;
+constexpr uint32_t kLdsFixed = 512 + 128 + 64 + 128 + 16;
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
     return (size_t)PW * 16 + (size_t)D * 4 + kLdsFixed + (((size_t)k * 8 + 15) & ~(size_t)15) + 16 * (kBeamLds + 1);
 }
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
     unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
     float* s_vec = reinterpret_cast<float*>(fixed);
-    float* s_exact = reinterpret_cast<float*>(fixed + 768);
-    uint8_t* s_list = fixed + 896;
-    float* s_slack = reinterpret_cast<float*>(fixed + 960);
-    double* s_ratio = reinterpret_cast<double*>(fixed + 1088);   // [2]
+    float* s_exact = reinterpret_cast<float*>(fixed + 512);
+    uint8_t* s_list = fixed + 640;
+    float* s_slack = reinterpret_cast<float*>(fixed + 704);
+    double* s_ratio = reinterpret_cast<double*>(fixed + 832);   // [2]
     Result* nn = reinterpret_cast<Result*>(fixed + kLdsFixed);
     // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
     const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
