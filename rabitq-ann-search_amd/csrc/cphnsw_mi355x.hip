@@ -450,6 +450,7 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
             stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15]);
 #endif
+    if (getenv("CPH_DEBUG_STATS")) fprintf(stderr, "[stats] expansions=%llu with_no_new_neighbour=%llu\n", stats[0], stats[7]);
     for (int i = 0; i < 6; ++i) h->last_stats[i] = stats[i];
     h->last_stats[5] = todo.size();
     h->last_stats[6] = (uint64_t)(ms * 1000.0);

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
         uint32_t log_count = 0;
         int slack_batch = 0;
         bool overflow = false;
-        uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0;
+        uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0, st_allseen = 0;
 #ifdef CPH_PHASE_TIMERS
         unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tlast = clock64();
@@ -460,8 +460,6 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 else dot = dot_generic;
                 exact_dist = exact_from_dot(qnorm, cur_norm, dot);
             }
-            LaneEst v;
-            bl.reduce(blk, a.L, qm, lane, v);
             st_exact++;
             st_exp++;
             if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
@@ -477,12 +475,36 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 continue;
             }
 
+            // ---- estimated set: result of the probe issued above --------------------------------
+            bool is_new = active && (old_bits & my_bit) == 0;
+            // a vertex whose neighbour list repeats an id: only the first copy is new
+            if ((a.flags & 1u) && __any(is_new)) {
+                // (graphs written by the reference never repeat an id; the loader sets the
+                // flag when one does, and only then is this screen paid for)
+                for (int j = 0; j < 31; ++j) {
+                    uint32_t oj = __shfl(nid, j);
+                    bool nj = __shfl((int)is_new, j) != 0;
+                    if (nj && lane > j && lane < 32 && oj == nid) is_new = false;
+                }
+            }
+            if (is_new) atomicOr(&bm[nid >> 5], my_bit);   // mark (two new ids may share a word)
+            const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
             // slack level schedule (:141-145)
             if (a.sc.num_slack > 0) {
                 int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
                 qp.slack = s_slack[lvl];
                 ++slack_batch;
             }
+            // Every neighbour already estimated (a quarter to a third of the expansions, most of
+            // them late in the search): the reference evaluates the block and then skips all 32
+            // neighbours (:227), so nothing it computes is observable -- the FastScan arithmetic,
+            // more than half of an expansion's vector instructions, is not issued at all.
+            if (new_mask == 0) {
+                ++st_allseen;
+                continue;
+            }
+            LaneEst v;
+            bl.reduce(blk, a.L, qm, lane, v);
             const float dqp = exact_dist;
             const float sq = __builtin_sqrtf(dqp);
 
@@ -503,20 +525,6 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             }
 
             CPH_TICK(2);
-            // ---- estimated set: result of the test-and-set issued above -------------------
-            bool is_new = active && (old_bits & my_bit) == 0;
-            // a vertex whose neighbour list repeats an id: only the first copy is new
-            if ((a.flags & 1u) && __any(is_new)) {
-                // (graphs written by the reference never repeat an id; the loader sets the
-                // flag when one does, and only then is this screen paid for)
-                for (int j = 0; j < 31; ++j) {
-                    uint32_t oj = __shfl(nid, j);
-                    bool nj = __shfl((int)is_new, j) != 0;
-                    if (nj && lane > j && lane < 32 && oj == nid) is_new = false;
-                }
-            }
-            if (is_new) atomicOr(&bm[nid >> 5], my_bit);   // mark (two new ids may share a word)
-            const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
             const bool warmup = nn_sz < k;  // (:210)
             bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
             const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
@@ -681,6 +689,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             atomicAdd(&a.stats[2], (unsigned long long)st_new);
             atomicAdd(&a.stats[3], (unsigned long long)st_push);
             atomicAdd(&a.stats[4], (unsigned long long)st_skip);
+            atomicAdd(&a.stats[7], (unsigned long long)st_allseen);
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);
 #endif
