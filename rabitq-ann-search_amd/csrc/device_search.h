@@ -4,16 +4,22 @@
 // helpers BoundedMaxHeap (:17-49) / BeamEntry (:53-58).  Results are bit-identical to the
 // reference: the data-parallel parts (FastScan block, estimated-set probes, speculative
 // exact L2 of every lane whose estimate beats the threshold at loop entry) run on all 64
-// lanes, while the order-dependent decisions of the 32-neighbour loop (:218-273) are
-// replayed by lane 0 in neighbour order with the reference's heap algorithms
-// (std::push_heap / pop_heap / sort_heap element movement, so ties break identically).
+// lanes; the beam's pop_heap is executed by the whole wave (beam_pop_wave); the
+// order-dependent decisions of the 32-neighbour loop (:218-273) are taken by all lanes at
+// once when no neighbour is reranked, and replayed by lane 0 in neighbour order otherwise --
+// always with the reference's heap algorithms (std::push_heap / pop_heap / sort_heap element
+// movement, so ties break identically).
 //
 // Observations that shape the kernel:
 //  * every node enters the beam at most once (each push is guarded by the estimated-set
 //    test), so the reference's second "visited" table is never observable — only the
 //    estimated set is kept (a per-slot bitmap, cleared by un-marking the logged ids);
 //  * in a non-warm-up expansion the result-heap threshold only decreases, so
-//    {est < worst at loop entry} is a superset of the lanes the serial loop will rerank.
+//    {est < worst at loop entry} is a superset of the lanes the serial loop will rerank;
+//  * an expansion whose neighbours are all estimated already has no observable effect beyond
+//    the result-heap push of the popped vertex: its FastScan arithmetic is skipped;
+//  * the kernel is instruction-issue bound: there is no software prefetch, the
+//    probe is a load (atomics only for new ids), shuffles are DPP / v_permlane32_swap.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -401,8 +407,8 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             }
             CPH_TICK(0);
 
-            // ---- neighbour ids first: the estimated-set probe (:227) is a dependent round
-            // trip, so it is issued before the arithmetic on the block ----------------------
+            // ---- this expansion's loads, then the estimated-set probe (:227), a dependent round
+            // trip that overlaps the exact distance and the result-heap push below ------------
             const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
             const float* vrow = a.raw + (size_t)cur_id * D;
             // Nothing that matters is in flight here (the previous expansion's prefetch is thousands
@@ -412,8 +418,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             // The popped vertex's own vector goes straight to LDS (LDS-DMA, 16 B per lane, one
             // instruction for the 512 B; the strided per-chain reads then come from LDS).  It is
-            // issued FIRST: loads retire in order, so the wait for the neighbour ids below also
-            // covers it.
+            // issued FIRST: loads retire in order, so retiring the other loads below also covers it.
             if constexpr (SD == 128) {
                 if (lane < 32) lds_dma16(vrow + 4 * lane, vec_off);
                 __builtin_amdgcn_sched_barrier(0);
