@@ -363,8 +363,9 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
         // entry: ep_est = exact_l2(ep); beam.push({ep_est, 0, ep}); mark estimated (:95-97)
         {
             const uint32_t ep = hd.entry;
+            const float enorm = a.norm_sq[ep];
             float dot = group_dot8_lo(qv, a.raw + (size_t)ep * D, D, lane & 7);
-            float ex = exact_from_dot(qnorm, a.norm_sq[ep], dot);
+            float ex = exact_from_dot(qnorm, enorm, dot);
             st_exact++;
             if (lane == 0) {
                 logi[0] = ep;
@@ -553,8 +554,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                     const uint32_t idx = have ? s_list[base + g] : 0;
                     const uint32_t cid_l = (uint32_t)__shfl((int)nid, (int)idx);
                     const uint32_t cid = have ? cid_l : cur_id;
+                    const float cnorm = a.norm_sq[cid];   // issued with the vector loads, not after them
                     float dot = group_dot8_lo(qv, a.raw + (size_t)cid * D, D, lane & 7);
-                    float ex = exact_from_dot(qnorm, a.norm_sq[cid], dot);
+                    float ex = exact_from_dot(qnorm, cnorm, dot);
+                    asm volatile("" ::"v"(ex));   // keeps the norm load out of the branch below
                     if (have && (lane & 7) == 0) s_exact[idx] = ex;
                 }
                 st_exact += n_cand;
