@@ -220,12 +220,20 @@ __device__ __forceinline__ void beam_pop_wave(const Beam& h, uint32_t size, int 
     // the path is a prefix of it -- p_t = (hp >> (d - t)) - 1.  The loop is scalar-only; each lane
     // then derives its own pair of path positions with two shifts.
     uint32_t hp = 1, d = 0;
-    while (hp - 1 < nint) {
-        const uint32_t hole = hp - 1;
-        const unsigned long long m = hole < 64 ? m0 : m1;
-        const uint32_t left = (uint32_t)(m >> (hole & 63)) & 1u;
-        hp = 2 * hp + 1 - left;
-        ++d;
+    if (nint <= 64) {                              // the usual case: one mask, three scalar ops less per level
+        while (hp - 1 < nint) {
+            const uint32_t left = (uint32_t)(m0 >> (hp - 1)) & 1u;
+            hp = 2 * hp + 1 - left;
+            ++d;
+        }
+    } else {
+        while (hp - 1 < nint) {
+            const uint32_t hole = hp - 1;
+            const unsigned long long m = hole < 64 ? m0 : m1;
+            const uint32_t left = (uint32_t)(m >> (hole & 63)) & 1u;
+            hp = 2 * hp + 1 - left;
+            ++d;
+        }
     }
     if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
         hp = 2 * hp;
@@ -305,7 +313,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
     lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
 
-    const uint32_t vec_off = lds_offset(s_vec);
+    // LDS byte offset of s_vec for the DMA's M0: the dynamic LDS starts right behind the kernel's static
+    // LDS (none here), so this is a compile-time constant -- a generic-to-LDS pointer cast would be
+    // re-derived (with its null check) by ten scalar instructions in every expansion
+    const uint32_t vec_off = __builtin_amdgcn_groupstaticsize() + PW * 16 + D * 4;
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
