@@ -232,6 +232,34 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+def test_results_do_not_depend_on_launch_order(gold):
+    """CPH_QUERY_ORDER=0 (queries handed out in batch order) against the same goldens, with fewer
+    slots than queries so that the order matters for the schedule."""
+    import subprocess
+    import sys
+    import os
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+from golden_util import DATASETS, fixture_path, golden
+import cphnsw_mi355x
+g = golden()
+for name, bits in (("g128", 4), ("sift96", 4), ("g16", 2)):
+    ix = cphnsw_mi355x.CPIndex(DATASETS[name]["dim"], bits)
+    ix.load(fixture_path(name, bits))
+    ix.set_search_params(slots=4, beam_capacity=0)
+    ids, d = ix.search_batch(g[f"Q/{name}"], 10)
+    assert np.array_equal(ids, g[f"S/{name}/b{bits}/plain/k10/ids"]), (name, bits)
+    assert d.tobytes() == g[f"S/{name}/b{bits}/plain/k10/d"].tobytes(), (name, bits)
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CPH_QUERY_ORDER="0")
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + code], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("variant", ["2", "4"])
 def test_alternative_search_kernels_are_bit_exact(gold, variant):
     """The alternative search kernels (2 = two queries per wavefront, 4 = register-resident heaps on
