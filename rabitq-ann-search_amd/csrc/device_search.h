@@ -264,9 +264,9 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512] (popped vertex's vector, LDS-DMA target) |
-// exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// pf[256] (prefetch sink, latency mode) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsFixed = 512 + 128 + 64 + 128 + 16;
+constexpr uint32_t kLdsFixed = 512 + 256 + 128 + 64 + 128 + 16;
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
     return (size_t)PW * 16 + (size_t)D * 4 + kLdsFixed + (((size_t)k * 8 + 15) & ~(size_t)15) + 16 * (kBeamLds + 1);
 }
@@ -282,6 +282,10 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
 }
 __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
+}
+
+__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_off) : "memory");
 }
 
 template <int BW, int SD>
@@ -304,10 +308,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
     unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
     float* s_vec = reinterpret_cast<float*>(fixed);
-    float* s_exact = reinterpret_cast<float*>(fixed + 512);
-    uint8_t* s_list = fixed + 640;
-    float* s_slack = reinterpret_cast<float*>(fixed + 704);
-    double* s_ratio = reinterpret_cast<double*>(fixed + 832);   // [2]
+    float* s_exact = reinterpret_cast<float*>(fixed + 768);
+    uint8_t* s_list = fixed + 896;
+    float* s_slack = reinterpret_cast<float*>(fixed + 960);
+    double* s_ratio = reinterpret_cast<double*>(fixed + 1088);   // [2]
     Result* nn = reinterpret_cast<Result*>(fixed + kLdsFixed);
     // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
     const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     // LDS (none here), so this is a compile-time constant -- a generic-to-LDS pointer cast would be
     // re-derived (with its null check) by ten scalar instructions in every expansion
     const uint32_t vec_off = __builtin_amdgcn_groupstaticsize() + PW * 16 + D * 4;
+    const uint32_t pf_off = vec_off + 512;
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
@@ -326,6 +331,13 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     const float FMAX = 3.402823466e+38f;
     if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
+    // Latency mode: a batch that fits the resident slots has no queue behind it -- bandwidth is free and
+    // every query is on the critical path, so the next beam top is prefetched as the reference does
+    // (:124-128).  With a queue behind the slots that prefetch only costs bandwidth (see below).
+    // (Switching to it when a larger batch starts to drain was tried: any way of telling thousands of
+    // running waves that the queue is empty -- polling the counter or a flag word -- cost far more than
+    // the prefetch gains in the drain phase.)
+    const bool lat = a.nq <= gridDim.x;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.counter, 1u);
@@ -462,11 +474,23 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
             if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (No software prefetch of the next vertex: the reference prefetches beam.top() at this
-            // point, :124-128, and so did this kernel -- but with thousands of queries in flight the
-            // latency is hidden anyway, and the ~40 % of predictions that a later push invalidates
-            // cost HBM bandwidth that at large batches is the scarcer resource: 22.9 -> 21.1 ms per
-            // 100k queries without it, 3.03 -> 2.85 ms per 10k.)
+            // Software prefetch of the next beam top, in latency mode only (see `lat`): one dword per
+            // 64-B line of its block and vector by LDS-DMA into a sink that is never read.  In the
+            // throughput phase the ~40 % of predictions that a later push invalidates cost HBM
+            // bandwidth that is the scarcer resource there (22.9 -> 21.1 ms per 100k queries without).
+            // The compiler does not know this load: it goes right behind the probe, the only load of
+            // this expansion still to be waited for (with vmcnt(0)).
+            if (lat && beam_size > 0) {
+                const uint32_t next_id = bcast_u32(heap.lds(0).z);
+                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
+                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
+                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
+                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
+                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
+                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
+                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
+                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
+            }
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
