@@ -109,6 +109,9 @@ int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
 int cph_last_search_stats(cph_index* h, uint64_t out[8]);
 /* Vertices expanded by each query of the last batch (its first pass); n = that batch's size. */
 int cph_last_query_expansions(cph_index* index, uint32_t* out, uint64_t n);
+/* Launch order of a batch (hook of the counting sort that hands queries out closest-entry-first):
+ * order[n] = permutation of 0..n-1, ascending in the top 14 bits of the non-negative float keys. */
+int cph_order_queries(cph_index* index, const float* keys, uint64_t n, uint32_t* order);
 
 /* ---- kernel-level hooks ------------------------------------------------------------ */
 /* Query encoder (encoder/rabitq_encoder.hpp:73-79,98-136,197-209): lut = u8[D/4][16] in

@@ -29,6 +29,7 @@ SYMBOLS = {
     "cph_set_search_params": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64]),
     "cph_last_search_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cph_last_query_expansions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "cph_order_queries": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "cph_encode_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cph_entry_point": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "cph_fastscan_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float,

@@ -132,6 +132,13 @@ class CPIndex:
         _lib.check(_lib.lib().cph_last_query_expansions(self._h, out.ctypes.data, int(n)))
         return out
 
+    def order_queries(self, keys):
+        """Launch order the search would use for these (non-negative) scheduling keys."""
+        keys = np.ascontiguousarray(keys, np.float32)
+        out = np.empty(len(keys), np.uint32)
+        _lib.check(_lib.lib().cph_order_queries(self._h, keys.ctypes.data, len(keys), out.ctypes.data))
+        return out
+
     def get_vectors(self, first=0, count=None):
         """Stored vectors of internal ids [first, first+count) as float32 (count, dim)."""
         if count is None:

@@ -641,6 +641,23 @@ int cph_last_query_expansions(cph_index* h, uint32_t* out, uint64_t n) {
     });
 }
 
+int cph_order_queries(cph_index* h, const float* keys, uint64_t n, uint32_t* order) {
+    return guarded([&] {
+        if (!h || !keys || !order) throw InvalidArg("null argument");
+        if (n == 0 || n > 0xFFFFFFFFull) throw InvalidArg("bad n");
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->use_device();
+        DevBuf<float> dk;
+        DevBuf<uint32_t> dord;
+        dk.alloc(n);
+        dord.alloc(n);
+        HIP_CHECK(hipMemcpy(dk.p, keys, n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, nullptr, dk.p, (uint32_t)n, dord.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpy(order, dord.p, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k, int64_t* ids,
                      float* dist) {
     return guarded([&] {

@@ -232,6 +232,23 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+@pytest.mark.parametrize("n", [1, 63, 1024, 10000, 70001])
+def test_order_kernel_is_a_sorted_permutation(cph, n):
+    """The counting sort behind the launch order: a permutation, ascending in the 14-bit bucket of
+    the key; zeros, denormals, huge values, infinities, negative and NaN keys included."""
+    ix = cph.CPIndex(16, 1)
+    rng = np.random.default_rng(n)
+    keys = (rng.gamma(2.0, 5000.0, n)).astype(np.float32)
+    special = np.array([0.0, 1e-45, 1e-30, 3.4e38, np.inf, -1.0, -0.0, np.nan], np.float32)
+    keys[: min(n, len(special))] = special[: min(n, len(special))]
+    order = ix.order_queries(keys)
+    assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+    bits = keys.view(np.uint32)
+    bucket = np.where(bits >> 31, 0, np.minimum(bits >> 17, 16383)).astype(np.int64)
+    b = bucket[order]
+    assert (b[1:] >= b[:-1]).all()
+
+
 def test_results_do_not_depend_on_launch_order(gold):
     """CPH_QUERY_ORDER=0 (queries handed out in batch order) against the same goldens, with fewer
     slots than queries so that the order matters for the schedule."""
