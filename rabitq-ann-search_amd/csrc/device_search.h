@@ -522,6 +522,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             if ((a.flags & 1u) && __any(is_new)) {
                 // (graphs written by the reference never repeat an id; the loader sets the
                 // flag when one does, and only then is this screen paid for)
+#pragma unroll 1   // cold path: rolled, or its 31 lane masks are hoisted and spilled for everyone
                 for (int j = 0; j < 31; ++j) {
                     uint32_t oj = __shfl(nid, j);
                     bool nj = __shfl((int)is_new, j) != 0;

@@ -232,6 +232,42 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+@pytest.mark.parametrize("name,bits", [("g128", 4), ("g16", 2)])
+def test_repeated_neighbour_ids(cph, oracle, gold, tmp_path, name, bits):
+    """A graph whose neighbour lists repeat an id (the reference never writes one, the loader flags
+    it): only the first copy of the id is new.  Fixture patched in place, GPU against the oracle."""
+    import gzip
+    from golden_util import vertex_layout
+    dim = DATASETS[name]["dim"]
+    n = DATASETS[name]["n"]
+    D = max(16, 1 << (dim - 1).bit_length())
+    src = fixture_path(name, bits)
+    data = bytearray(gzip.open(src, "rb").read() if src.endswith(".gz") else open(src, "rb").read())
+    vb, nb_off, codes = vertex_layout(D, bits)
+    base = 68 + 248 + 72 + dim * 4 + n * 4 + n * 4 + n * D * 4
+    ids_off = nb_off + codes + 3 * 128 + 64 + (64 if bits > 1 else 0)
+    patched = 0
+    for v in range(0, n, 3):
+        o = base + v * vb + ids_off
+        cnt = int.from_bytes(data[o + 128:o + 132], "little")
+        if cnt >= 8:
+            data[o + 5 * 4:o + 6 * 4] = data[o + 2 * 4:o + 3 * 4]      # slot 5 repeats slot 2
+            data[o + 7 * 4:o + 8 * 4] = data[o + 0 * 4:o + 1 * 4]      # slot 7 repeats slot 0
+            patched += 1
+    assert patched > 50
+    p = str(tmp_path / "dups.idx")
+    open(p, "wb").write(bytes(data))
+    oi = oracle.load(p)
+    ix = cph.CPIndex(dim, bits)
+    ix.load(p)
+    Q = gold[f"Q/{name}"]
+    for k in (10, 100):
+        oids, od, ocnt = oi.search_batch(Q, k)
+        ids, d = ix.search_batch(Q, k)
+        assert np.array_equal(ids, oids), (name, bits, k)
+        assert _beq(d, od), (name, bits, k)
+
+
 @pytest.mark.parametrize("n", [1, 63, 1024, 10000, 70001])
 def test_order_kernel_is_a_sorted_permutation(cph, n):
     """The counting sort behind the launch order: a permutation, ascending in the 14-bit bucket of
