@@ -249,8 +249,17 @@ void upload_index(cph_index* h) {
     for (int l = 0, m = 0; l < nl; ++l) {
         const uint32_t* dmap = nullptr;
         if (hi.upper[l].size() > 16) {
+            // vertex -> first edge | degree << 26 (the encoder then needs neither `nodes` nor `offsets`)
             row_of.assign(n, kInvalidNode);
-            for (size_t r = 0; r < hi.upper[l].size(); ++r) row_of[hi.upper[l][r].node] = (uint32_t)r;
+            uint64_t first = 0;
+            bool fits = true;
+            for (size_t r = 0; r < hi.upper[l].size(); ++r) {
+                const uint64_t deg = hi.upper[l][r].nbrs.size();
+                if (first >= (1u << 26) || deg > 62) { fits = false; break; }
+                row_of[hi.upper[l][r].node] = (uint32_t)first | ((uint32_t)deg << 26);
+                first += deg;
+            }
+            if (!fits) { h->layers[l] = UpperLayerDev{h->d_upper.p + off_nodes[l], h->d_upper.p + off_offs[l], h->d_upper.p + off_nbrs[l], nullptr, (uint32_t)hi.upper[l].size()}; ++m; continue; }
             HIP_CHECK(hipMemcpy(h->d_row_of.p + (size_t)m * n, row_of.data(), n * 4, hipMemcpyHostToDevice));
             dmap = h->d_row_of.p + (size_t)m * n;
             ++m;

@@ -20,7 +20,8 @@ struct UpperLayerDev {       // CSR of one upper layer, nodes sorted ascending (
     const uint32_t* nodes;   // [n_nodes]
     const uint32_t* offsets; // [n_nodes + 1]
     const uint32_t* nbrs;
-    const uint32_t* row_of;  // [n] vertex -> row in `nodes` (kInvalidNode if absent), or null: binary search
+    const uint32_t* row_of;  // [n] vertex -> first edge | degree << 26 (kInvalidNode if absent), or null:
+                             // binary search over `nodes` + `offsets`
     uint32_t n_nodes;
 };
 
@@ -137,36 +138,53 @@ __global__ __launch_bounds__(64) void encode_kernel(EncodeArgs a) {
         if (a.max_level > 0 && ep < a.n) {
             for (int level = a.max_level; level >= 1; --level) {
                 const UpperLayerDev& Ly = a.layers[level - 1];
-                float best = group_l2sq8(qv, a.raw + (size_t)ep * D, D, lane & 7);
+                // distance to the layer's entry: the previous layer's winner, whose distance is already
+                // known (same query, same vector, same arithmetic => same float as recomputing it)
+                float best = (level == a.max_level) ? group_l2sq8(qv, a.raw + (size_t)ep * D, D, lane & 7) : ep_dist;
                 uint32_t best_id = ep;
                 bool improved = true;
                 while (improved) {
                     improved = false;
-                    // find_edge: lower_bound over the sorted node list (uniform across lanes)
-                    uint32_t lo = 0, hi = Ly.n_nodes;
+                    float cand = 3.402823466e+38f;
+                    uint32_t cand_id = kInvalidNode;
+                    uint32_t cand_pos = 0xFFFFFFFFu;
                     if (Ly.row_of) {
-                        // dense vertex -> row map: one load instead of log2(n_nodes) dependent ones
-                        lo = Ly.row_of[best_id];
-                        if (lo == kInvalidNode) break;
+                        // dense vertex -> (first edge, degree) map, then the whole neighbour list in one
+                        // load: two dependent round trips per hop ahead of the vectors instead of
+                        // log2(n_nodes) + 1 + one per pass
+                        const uint32_t info = Ly.row_of[best_id];
+                        if (info == kInvalidNode) break;
+                        const uint32_t beg = info & 0x03FFFFFFu, cnt = info >> 26;
+                        const uint32_t mine = (uint32_t)lane < cnt ? Ly.nbrs[beg + lane] : best_id;
+                        // (issuing the loads of all passes together was tried: 150 VGPRs, 3 waves per
+                        // SIMD, and the kernel got slower -- occupancy x latency stays the same product)
+                        for (uint32_t base = 0; base < cnt; base += 8) {
+                            const uint32_t pos = base + (lane >> 3);
+                            const bool have = pos < cnt;
+                            const uint32_t nb = (uint32_t)__shfl((int)mine, (int)(have ? pos : 0));
+                            const float d = group_l2sq8(qv, a.raw + (size_t)(have ? nb : best_id) * D, D, lane & 7);
+                            if (have && (d < cand || (d == cand && pos < cand_pos))) {
+                                cand = d; cand_id = nb; cand_pos = pos;
+                            }
+                        }
                     } else {
+                        // find_edge: lower_bound over the sorted node list (uniform across lanes)
+                        uint32_t lo = 0, hi = Ly.n_nodes;
                         while (lo < hi) {
                             const uint32_t mid = (lo + hi) >> 1;
                             if (Ly.nodes[mid] < best_id) lo = mid + 1; else hi = mid;
                         }
                         if (lo >= Ly.n_nodes || Ly.nodes[lo] != best_id) break;
-                    }
-                    const uint32_t beg = Ly.offsets[lo], end = Ly.offsets[lo + 1];
-                    // neighbours in stored order; strict improvement => the first minimum wins
-                    float cand = 3.402823466e+38f;
-                    uint32_t cand_id = kInvalidNode;
-                    uint32_t cand_pos = 0xFFFFFFFFu;
-                    for (uint32_t base = beg; base < end; base += 8) {
-                        const uint32_t pos = base + (lane >> 3);
-                        const bool have = pos < end;
-                        const uint32_t nb = have ? Ly.nbrs[pos] : best_id;
-                        const float d = group_l2sq8(qv, a.raw + (size_t)nb * D, D, lane & 7);
-                        if (have && (d < cand || (d == cand && pos < cand_pos))) {
-                            cand = d; cand_id = nb; cand_pos = pos;
+                        const uint32_t beg = Ly.offsets[lo], end = Ly.offsets[lo + 1];
+                        // neighbours in stored order; strict improvement => the first minimum wins
+                        for (uint32_t base = beg; base < end; base += 8) {
+                            const uint32_t pos = base + (lane >> 3);
+                            const bool have = pos < end;
+                            const uint32_t nb = have ? Ly.nbrs[pos] : best_id;
+                            const float d = group_l2sq8(qv, a.raw + (size_t)nb * D, D, lane & 7);
+                            if (have && (d < cand || (d == cand && pos < cand_pos))) {
+                                cand = d; cand_id = nb; cand_pos = pos;
+                            }
                         }
                     }
                     for (int o = 8; o < 64; o <<= 1) {
