@@ -348,8 +348,21 @@ __device__ __forceinline__ float chain_dot(const float* q_lds, int j, const floa
 // the same chain with both operands in LDS (v staged there by an LDS-DMA load)
 template <int N>
 __device__ __forceinline__ float chain_dot_lds(const float* q_lds, const float* v_lds, int j, float c) {
+    // eight elements of both operands are read before the FMAs that use them (two LDS round trips for
+    // N = 16 instead of one per pair of FMAs); the chain order itself is unchanged
+    static_assert(N % 8 == 0, "chain length");
 #pragma unroll
-    for (int i = 0; i < N; ++i) c = __fmaf_rn(q_lds[j + 8 * i], v_lds[j + 8 * i], c);
+    for (int base = 0; base < N; base += 8) {
+        float q[8], v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            q[i] = q_lds[j + 8 * (base + i)];
+            v[i] = v_lds[j + 8 * (base + i)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c = __fmaf_rn(q[i], v[i], c);
+    }
     return c;
 }
 template <int N>
