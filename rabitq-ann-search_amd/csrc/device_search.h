@@ -405,6 +405,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             CPH_TICK(7);
             if (beam_size == 0) break;
             uint32_t cur_id;
+            float worst_pop;   // result-heap threshold as read by the pop (wave-uniform)
             {
                 // every LDS read the pop needs first goes out together: the top, the result-heap
                 // threshold, and (inside beam_pop_wave) the re-inserted entry and the child keys
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 verdict = bcast_u32(verdict);   // every lane read the same words: make it provably uniform
                 if (verdict == 0) break;
                 if (verdict == 1) continue;
+                worst_pop = bcast_f32(worst);
             }
             CPH_TICK(0);
 
@@ -503,11 +505,18 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             }
             st_exact++;
             st_exp++;
-            if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
-            nn_size = bcast_u32(nn_size);
-            __builtin_amdgcn_wave_barrier();
+            // BoundedMaxHeap::push changes the heap only while it is filling or when the new distance
+            // beats the threshold: both are wave-uniform facts, so the three expansions out of four
+            // that leave it alone skip the lane-0 section and the re-read of the threshold
+            float worst0 = worst_pop;
+            const bool nn_changes = bcast_u32((nn_size < k || exact_dist < worst_pop) ? 1u : 0u) != 0u;   // provably uniform
+            if (nn_changes) {
+                if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
+                nn_size = bcast_u32(nn_size);
+                __builtin_amdgcn_wave_barrier();
+                worst0 = bcast_f32(nn_size ? nn[0].dist : FMAX);
+            }
             const uint32_t nn_sz = nn_size;
-            const float worst0 = bcast_f32(nn_sz ? nn[0].dist : FMAX);
             CPH_TICK(1);
             if (!__any(active)) {  // n_neighbors == 0 (:137)
                 // (retire the probe's destination register on this path too: a load left pending
