@@ -84,11 +84,18 @@ int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k,
                      int64_t* ids, float* dist);
 
 /* Same, but queries/ids/dist are DEVICE pointers on the handle's device and the work is
- * enqueued on `stream` (a hipStream_t; NULL = default stream).  Nothing is copied to the
- * host; returns after enqueueing unless a capacity overflow forces a re-run (then it
- * synchronises the stream). */
+ * enqueued on `stream` (a hipStream_t; NULL = default stream).  Nothing is copied to the host and
+ * the call returns after enqueueing, always: a query that outgrows its scratch capacity is
+ * answered exactly by a full-capacity re-run launch enqueued behind the main one.  The results are
+ * complete when `stream` reaches the point behind this call.  A handle keeps two sets of batch
+ * scratch and uses them alternately, so two batches enqueued on two different streams run
+ * concurrently (the second fills the GPU while the first drains its longest queries); a third
+ * call waits, on its stream, for the batch that used its set before.  d_queries must stay valid
+ * until the batch has run. */
 int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, uint64_t k,
                             int64_t* d_ids, float* d_dist, void* stream);
+/* Blocks the calling host thread until every batch enqueued on this handle has finished. */
+int cph_synchronize(cph_index* h);
 
 /* Single query; writes m <= max(k,1) results (unpadded, src/bindings.cpp:146-175). */
 int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
@@ -102,11 +109,14 @@ int cph_get_vectors(cph_index* h, uint64_t first, uint64_t count, float* out);
 /* Tuning knobs (0 = automatic): resident query slots and per-slot beam capacity. */
 int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
 
-/* Per-batch work counters of the last search on this handle (sums over queries):
- * out[0]=expansions (FastScan blocks), [1]=exact L2 evaluations, [2]=new neighbours,
- * [3]=beam pushes, [4]=stage-2 skipped batches, [5]=queries re-run after overflow,
- * [6]=kernel time of the last search in microseconds (HIP events), [7]=reserved. */
-int cph_last_search_stats(cph_index* h, uint64_t out[8]);
+/* Per-batch work counters of the last search enqueued on this handle (sums over queries; waits
+ * for that batch): out[0]=expansions (FastScan blocks), [1]=exact L2 evaluations, [2]=new
+ * neighbours, [3]=beam pushes, [4]=stage-2 skipped batches, [5]=queries re-run after a capacity
+ * overflow, [6]=device time of the search launches in microseconds (HIP events on the launch
+ * stream; with two batches in flight it includes the time shared with the other one),
+ * [7]=expansions whose 32 neighbours were all estimated already, [8]=resident query slots used,
+ * [9]=per-slot capacity, [10..11]=reserved (0). */
+int cph_last_search_stats(cph_index* h, uint64_t out[12]);
 /* Vertices expanded by each query of the last batch (its first pass); n = that batch's size. */
 int cph_last_query_expansions(cph_index* index, uint32_t* out, uint64_t n);
 /* Launch order of a batch (hook of the counting sort that hands queries out closest-entry-first):

@@ -75,18 +75,29 @@ class CPIndex:
 
     def search_batch_device(self, queries, k=DEFAULT_K, out=None, stream=None):
         """Device-resident variant: `queries` is a float32 CUDA/HIP torch tensor (n, dim) on this
-        index' device; returns (ids int64, dist float32) torch tensors on the same device."""
+        index' device; returns (ids int64, dist float32) torch tensors on the same device.  The work
+        is enqueued on `stream` (default: torch's current stream) and the call does not wait for it:
+        the tensors are valid in stream order.  Two batches on two streams overlap."""
         import torch
         if queries.dim() != 2 or queries.shape[1] != self._dim or queries.dtype != torch.float32:
             raise ValueError("queries must be a (n, dim) array")
         queries = queries.contiguous()
         n, k = queries.shape[0], int(k)
+        if not queries.is_cuda or queries.device.index != self._device:
+            raise ValueError("queries must live on this index' device")
         if out is None:
             ids = torch.empty((n, k), dtype=torch.int64, device=queries.device)
             dist = torch.empty((n, k), dtype=torch.float32, device=queries.device)
         else:
             ids, dist = out
-        st = torch.cuda.current_stream(queries.device).cuda_stream if stream is None else stream
+            for t, dt in ((ids, torch.int64), (dist, torch.float32)):
+                if (tuple(t.shape) != (n, k) or t.dtype != dt or t.device != queries.device
+                        or not t.is_contiguous()):
+                    raise ValueError("out must be contiguous (n, k) int64 / float32 tensors on the queries' device")
+        if stream is None:
+            st = torch.cuda.current_stream(queries.device).cuda_stream
+        else:
+            st = getattr(stream, "cuda_stream", stream)
         _lib.check(_lib.lib().cph_search_batch_device(self._h, queries.data_ptr(), n, k, ids.data_ptr(),
                                                       dist.data_ptr(), C.c_void_p(st)))
         return ids, dist
@@ -120,11 +131,15 @@ class CPIndex:
         _lib.check(_lib.lib().cph_set_search_params(self._h, int(slots), int(beam_capacity)))
 
     def last_search_stats(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         _lib.check(_lib.lib().cph_last_search_stats(self._h, out))
         keys = ("expansions", "exact_l2", "new_neighbours", "beam_pushes", "stage2_skipped",
-                "rerun_queries", "kernel_us", "slots_cap")
+                "rerun_queries", "kernel_us", "expansions_nothing_new", "slots", "capacity")
         return dict(zip(keys, [int(x) for x in out]))
+
+    def synchronize(self):
+        """Waits for every batch enqueued with search_batch_device."""
+        _lib.check(_lib.lib().cph_synchronize(self._h))
 
     def last_query_expansions(self, n):
         """Vertices expanded by each of the n queries of the last batch."""

@@ -21,8 +21,6 @@
 #include "device_encode.h"
 #include "device_fastscan.h"
 #include "device_search.h"
-#include "device_search2.h"
-#include "device_search4.h"
 #include "device_stream.h"
 #include "host_index.h"
 #include "builder_pipeline.h"
@@ -127,6 +125,35 @@ void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, s
 
 }  // namespace
 
+// One in-flight batch: query staging, outputs, statistics and per-slot scratch.  A handle owns two,
+// used alternately, so that a batch enqueued on one stream can start while the previous one (on
+// another stream) is still draining its longest queries.
+struct BatchSet {
+    DevBuf<float> d_queries_raw, d_queries, d_entry_dist, d_dist;
+    DevBuf<uint4> d_qmasks;
+    DevBuf<QueryHeader> d_qhdr;
+    DevBuf<int64_t> d_ids;
+    DevBuf<uint32_t> d_count, d_status, d_order, d_redo;
+    // u64 words: [0..15] counters | [16] lo = work-queue counter, hi = length of the re-run list |
+    // [17] lo = work-queue counter of the re-run launch
+    DevBuf<unsigned long long> d_stats;
+    unsigned long long* pin_stats = nullptr;   // pinned host copy, written at the end of every batch
+    // per-slot scratch (estimated-set bitmap, beam spill area, id log), `cap` entries per slot
+    DevBuf<uint32_t> d_bitmaps, d_logids;
+    DevBuf<uint4> d_beam;
+    uint32_t slots = 0;
+    uint64_t cap = 0;
+    // full-capacity (n + 1) scratch of the overflow re-run launch
+    DevBuf<uint32_t> r_bitmaps, r_logids;
+    DevBuf<uint4> r_beam;
+    uint32_t r_slots = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    bool used = false;        // a batch has been enqueued on this set (ev_done is meaningful)
+    uint32_t nq = 0;          // size of that batch
+    uint32_t run_slots = 0;   // slots its search launch used
+};
+constexpr int kStatWords = 18;
+
 struct cph_index {
     uint64_t dim = 0;
     uint32_t bits = 0;
@@ -143,39 +170,25 @@ struct cph_index {
     int num_cus = 256;
     bool waves_from_env = false;
     uint32_t waves_per_cu = 4 * CPH_SEARCH_WAVES_PER_SIMD;  // resident waves per CU (launch bounds of the search kernel)
-    int kernel_variant = 1;            // 1 = LDS heaps, one query per wave; 2 = two queries per wave; 4 = register heaps
     // device-resident index
     DevBuf<uint8_t> d_blocks;
     DevBuf<float> d_raw, d_norm;
     // per-query feeders on the device: rotation signs + upper layers (CSR)
     DevBuf<float> d_signs;
     DevBuf<uint32_t> d_upper;          // all layers' nodes | offsets | nbrs, concatenated
+    DevBuf<uint32_t> d_row_of;
     UpperLayerDev layers[kMaxUpperLayers];
     int32_t dev_max_level = 0;
     float norm_factor = 0.0f, inv_sqrt_d = 0.0f;
-    // per-batch query staging + outputs
-    DevBuf<float> d_queries_raw;
-    DevBuf<float> d_queries;
-    DevBuf<uint4> d_qmasks;
-    DevBuf<QueryHeader> d_qhdr;
-    DevBuf<int64_t> d_ids;
-    DevBuf<float> d_dist;
-    DevBuf<uint32_t> d_count, d_status, d_todo, d_order, d_row_of;
-    DevBuf<float> d_entry_dist;
-    bool order_queries = true;   // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
-    uint32_t last_nq = 0;                    // size of the last batch (d_status holds its per-query words)
-    unsigned long long* pin_stats = nullptr; // pinned host copy of the statistics block
-    DevBuf<unsigned long long> d_stats;
-    // per-slot scratch
-    DevBuf<uint32_t> d_bitmaps, d_logids;
-    DevBuf<uint4> d_beam;
-    uint32_t scratch_slots = 0;
-    uint64_t scratch_cap = 0;
+    BatchSet sets[2];
+    int last_set = 1;                  // the set handed out last (the two alternate)
+    int last_search = -1;              // the set the most recent search went to
+    hipStream_t own_stream = nullptr;  // host-API calls (cph_search_batch, cph_search, hooks)
+    bool order_queries = true;         // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
     // knobs
     uint32_t want_slots = 0;
     uint64_t want_cap = 0;
-    uint64_t last_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t auto_cap = 0;             // grown when a batch had to re-run queries
     std::mutex mu;
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
@@ -189,8 +202,21 @@ void require_finalized(cph_index* h) {
     if (!h->finalized) throw std::runtime_error("Search failed: invalid entry point after finalize.");
 }
 
+void release_scratch(BatchSet& s) {
+    s.d_bitmaps.release(); s.d_logids.release(); s.d_beam.release();
+    s.r_bitmaps.release(); s.r_logids.release(); s.r_beam.release();
+    s.slots = 0; s.cap = 0; s.r_slots = 0;
+}
+
+// Waits (on the host) until nothing enqueued on this handle is running any more.
+void quiesce(cph_index* h) {
+    for (auto& s : h->sets)
+        if (s.used && s.ev_done) HIP_CHECK(hipEventSynchronize(s.ev_done));
+}
+
 void upload_index(cph_index* h) {
     h->use_device();
+    quiesce(h);
     const HostIndex& hi = h->host;
     h->L = make_dev_layout((uint32_t)hi.D, (uint32_t)hi.bw);
     h->sc = hi.consts();
@@ -200,7 +226,7 @@ void upload_index(cph_index* h) {
     h->d_blocks.alloc(n * stride + 64);
     h->d_raw.alloc(n * hi.D);
     h->d_norm.alloc(n);
-    // repack in chunks through a pinned staging buffer
+    // repack in chunks through a staging buffer
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (256u << 20) / stride));
     std::vector<uint8_t> stage(chunk * stride);
     for (size_t base = 0; base < n; base += chunk) {
@@ -267,31 +293,48 @@ void upload_index(cph_index* h) {
         h->layers[l] = UpperLayerDev{h->d_upper.p + off_nodes[l], h->d_upper.p + off_offs[l],
                                      h->d_upper.p + off_nbrs[l], dmap, (uint32_t)hi.upper[l].size()};
     }
-    h->scratch_slots = 0;
-    h->scratch_cap = 0;
+    for (auto& s : h->sets) release_scratch(s);
+    h->auto_cap = 0;
+    h->last_search = -1;
 }
 
-void ensure_scratch(cph_index* h, uint32_t slots, uint64_t cap) {
-    if (h->scratch_slots >= slots && h->scratch_cap == cap) return;
-    const uint64_t bm_words = (h->host.n + 31) / 32;
-    h->d_bitmaps.alloc((size_t)slots * bm_words);
-    HIP_CHECK(hipMemset(h->d_bitmaps.p, 0, (size_t)slots * bm_words * 4));
-    h->d_logids.alloc((size_t)slots * cap);
-    h->d_beam.alloc((size_t)slots * cap);
-    h->scratch_slots = slots;
-    h->scratch_cap = cap;
+// Picks the set for the next batch (the two alternate) and makes `st` wait for the batch that
+// used it before.  If that batch had to re-run queries, later batches get a larger capacity.
+BatchSet& next_set(cph_index* h, hipStream_t st) {
+    h->last_set ^= 1;
+    BatchSet& s = h->sets[h->last_set];
+    if (!s.ev0) {
+        HIP_CHECK(hipEventCreate(&s.ev0));
+        HIP_CHECK(hipEventCreate(&s.ev1));
+        HIP_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.pin_stats), kStatWords * 8, hipHostMallocDefault));
+        std::memset(s.pin_stats, 0, kStatWords * 8);
+    }
+    if (s.used) {
+        if (hipEventQuery(s.ev_done) == hipSuccess) {
+            if (s.pin_stats[5] != 0 && s.cap < h->host.n + 1)
+                h->auto_cap = std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(h->host.n + 1, s.cap * 4));
+        }
+        HIP_CHECK(hipStreamWaitEvent(st, s.ev_done, 0));
+    }
+    return s;
 }
 
 // Encode the queries on the device (rotation, 4-bit scalars -> masks, coefficients) and run the
 // upper-layer descent; d_raw_q = [nq][dim] raw queries already in HBM.
-void stage_queries(cph_index* h, const float* d_raw_q, uint64_t nq, hipStream_t st) {
+void stage_queries(cph_index* h, BatchSet& s, const float* d_raw_q, uint64_t nq, hipStream_t st) {
     const HostIndex& hi = h->host;
     const uint32_t D = (uint32_t)hi.D, PW = h->L.PW;
-    h->d_queries.alloc(nq * D);
-    h->d_qmasks.alloc(nq * PW);
-    h->d_qhdr.alloc(nq);
-    h->d_entry_dist.alloc(nq);
-    h->d_order.alloc(nq);
+    if (hi.entry == kInvalidNode || hi.entry >= hi.n)
+        throw std::runtime_error("Search failed: invalid entry point after finalize.");
+    if (s.d_queries.n < nq * D || s.d_qmasks.n < nq * PW || s.d_qhdr.n < nq) {
+        if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));   // growing: the old buffers must be idle
+        s.d_queries.alloc(nq * D);
+        s.d_qmasks.alloc(nq * PW);
+        s.d_qhdr.alloc(nq);
+        s.d_entry_dist.alloc(nq);
+        s.d_order.alloc(nq);
+    }
     EncodeArgs a{};
     a.queries_raw = d_raw_q;
     a.nq = (uint32_t)nq;
@@ -306,27 +349,54 @@ void stage_queries(cph_index* h, const float* d_raw_q, uint64_t nq, hipStream_t 
     a.entry = hi.entry;
     a.max_level = h->dev_max_level;
     for (int l = 0; l < kMaxUpperLayers; ++l) a.layers[l] = h->layers[l];
-    a.queries_padded = h->d_queries.p;
-    a.qmasks = h->d_qmasks.p;
-    a.qhdr = h->d_qhdr.p;
-    a.entry_dist = h->d_entry_dist.p;
-    if (hi.entry == kInvalidNode || hi.entry >= hi.n)
-        throw std::runtime_error("Search failed: invalid entry point after finalize.");
+    a.queries_padded = s.d_queries.p;
+    a.qmasks = s.d_qmasks.p;
+    a.qhdr = s.d_qhdr.p;
+    a.entry_dist = s.d_entry_dist.p;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)h->num_cus * 32);
     hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(64), encode_lds_bytes(D), st, a);
     HIP_CHECK(hipGetLastError());
 }
 
-// host queries -> device staging buffer
-const float* upload_queries(cph_index* h, const float* queries, uint64_t nq, hipStream_t st) {
-    h->d_queries_raw.alloc(nq * h->dim);
-    HIP_CHECK(hipMemcpyAsync(h->d_queries_raw.p, queries, nq * h->dim * 4, hipMemcpyHostToDevice, st));
-    return h->d_queries_raw.p;
+// host queries -> the set's staging buffer
+const float* upload_queries(cph_index* h, BatchSet& s, const float* queries, uint64_t nq, hipStream_t st) {
+    if (s.d_queries_raw.n < nq * h->dim) {
+        if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+        s.d_queries_raw.alloc(nq * h->dim);
+    }
+    HIP_CHECK(hipMemcpyAsync(s.d_queries_raw.p, queries, nq * h->dim * 4, hipMemcpyHostToDevice, st));
+    return s.d_queries_raw.p;
 }
 
-void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                   const uint32_t* d_todo, uint32_t slots, uint64_t cap, hipStream_t st,
-                   bool reset_counter) {
+// (Re)allocates the per-slot scratch of a set; the set must be idle.
+void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hipStream_t st) {
+    const uint64_t n = h->host.n;
+    const uint64_t bm_words = (n + 31) / 32;
+    if (!(s.slots >= slots && s.cap == cap)) {
+        if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+        s.d_bitmaps.alloc((size_t)slots * bm_words);
+        HIP_CHECK(hipMemsetAsync(s.d_bitmaps.p, 0, (size_t)slots * bm_words * 4, st));
+        s.d_logids.alloc((size_t)slots * cap);
+        s.d_beam.alloc((size_t)slots * cap);
+        s.slots = slots;
+        s.cap = cap;
+    }
+    // the overflow re-run needs room for every vertex: a few full-capacity slots
+    if (cap < n + 1 && s.r_slots == 0) {
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t per = (n + 1) * 20 + bm_words * 4;
+        const uint32_t rs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (uint64_t)(free_b * 0.25) / per));
+        s.r_bitmaps.alloc((size_t)rs * bm_words);
+        HIP_CHECK(hipMemsetAsync(s.r_bitmaps.p, 0, (size_t)rs * bm_words * 4, st));
+        s.r_logids.alloc((size_t)rs * (n + 1));
+        s.r_beam.alloc((size_t)rs * (n + 1));
+        s.r_slots = rs;
+    }
+}
+
+void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
+                   const uint32_t* d_todo, bool rerun, hipStream_t st) {
     SearchArgs a{};
     a.blocks = h->d_blocks.p;
     a.raw = h->d_raw.p;
@@ -334,54 +404,64 @@ void launch_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float*
     a.n = h->host.n;
     a.L = h->L;
     a.flags = h->flags;
-    a.queries = h->d_queries.p;
-    a.qmasks = h->d_qmasks.p;
-    a.qhdr = h->d_qhdr.p;
-    a.todo = d_todo;
-    a.nq = nq;
+    a.queries = s.d_queries.p;
+    a.qmasks = s.d_qmasks.p;
+    a.qhdr = s.d_qhdr.p;
     a.k = k;
     a.sc = h->sc;
-    // the work-queue counter sits right behind the 16 statistics words: one memset clears both
-    a.counter = reinterpret_cast<uint32_t*>(h->d_stats.p + 16);
-    a.cap = cap;
     a.bm_words = (h->host.n + 31) / 32;
-    a.bitmaps = h->d_bitmaps.p;
-    a.beam = h->d_beam.p;
-    a.log_ids = h->d_logids.p;
     a.out_ids = d_ids;
     a.out_dist = d_dist;
-    a.out_count = h->d_count.p;
-    a.status = h->d_status.p;
-    a.stats = h->d_stats.p;
-    if (reset_counter) HIP_CHECK(hipMemsetAsync(h->d_stats.p + 16, 0, 8, st));
-    if (h->kernel_variant == 4 && k <= kRegNn) {
-        const size_t lds = search4_lds_bytes(h->L.D, h->L.PW);
-        CPH_LAUNCH(search_kernel4, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
-    } else if (h->kernel_variant == 2) {
-        const size_t lds = search2_lds_bytes(h->L.D, h->L.PW, k);
-        if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
-        CPH_LAUNCH(search_kernel2, h->bits, h->L.D, dim3((slots + 1) / 2), dim3(64), lds, st, a);
+    a.out_count = s.d_count.p;
+    a.status = s.d_status.p;
+    a.stats = s.d_stats.p;
+    uint32_t* words = reinterpret_cast<uint32_t*>(s.d_stats.p + 16);   // [0] queue, [1] re-run list length, [2] re-run queue
+    uint32_t grid;
+    if (!rerun) {
+        a.todo = d_todo;
+        a.nq = nq;
+        a.counter = words;
+        a.cap = s.cap;
+        a.bitmaps = s.d_bitmaps.p;
+        a.beam = s.d_beam.p;
+        a.log_ids = s.d_logids.p;
+        a.redo = s.cap < h->host.n + 1 ? s.d_redo.p : nullptr;
+        a.redo_count = words + 1;
+        grid = s.run_slots;
     } else {
-        const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
-        if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
-        CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(slots), dim3(64), lds, st, a);
+        a.todo = s.d_redo.p;
+        a.nq = 0;
+        a.nq_dev = words + 1;
+        a.counter = words + 2;
+        a.cap = h->host.n + 1;
+        a.bitmaps = s.r_bitmaps.p;
+        a.beam = s.r_beam.p;
+        a.log_ids = s.r_logids.p;
+        grid = s.r_slots;
     }
+    const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
+    if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+    CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(grid), dim3(64), lds, st, a);
 }
 
-// Core: queries already staged in d_queries/d_qmasks/d_qhdr; results into device buffers.
-void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                hipStream_t st) {
+// Core: queries already staged in the set; results into device buffers.  Everything is enqueued on
+// `st` and nothing waits for the device: a query that outgrows its scratch is answered by the
+// full-capacity re-run launch that always follows the main one (it finds an empty list otherwise).
+void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
+                    hipStream_t st) {
     const uint64_t n = h->host.n;
-    h->d_count.alloc(nq);
-    h->d_status.alloc(nq);
-    h->d_stats.alloc(17);
-    if (!h->pin_stats) HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->pin_stats), 128, hipHostMallocDefault));
-    HIP_CHECK(hipMemsetAsync(h->d_stats.p, 0, 136, st));
+    if (s.d_count.n < nq) {
+        if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+        s.d_count.alloc(nq);
+        s.d_status.alloc(nq);
+        s.d_redo.alloc(nq);
+    }
+    s.d_stats.alloc(kStatWords);
+    HIP_CHECK(hipMemsetAsync(s.d_stats.p, 0, kStatWords * 8, st));
     // resident query slots: one wave each
-    const uint32_t qpw = h->kernel_variant == 2 ? 2u : 1u;   // query slots per wave
     uint32_t wpc = h->waves_per_cu;
-    if (h->kernel_variant == 1 && !h->waves_from_env) wpc = 4 * (h->L.D == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD);
-    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc * qpw;
+    if (!h->waves_from_env) wpc = 4 * (h->L.D == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD);
+    const uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc;
     // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
     // would leave 56% of the slots idle during the third round)
     const uint32_t rounds = (nq + max_slots - 1) / max_slots;
@@ -390,80 +470,43 @@ void run_search(cph_index* h, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_
     // short queries at the end of the order fill the gaps
     const bool ordered = h->dev_max_level > 0 && h->order_queries;
     if (ordered) slots = std::min<uint32_t>(nq, max_slots);
-    slots = (slots + qpw - 1) / qpw * qpw;
-    size_t free_b = 0, total_b = 0;
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
-    uint64_t cap = h->want_cap ? h->want_cap : std::min<uint64_t>(n + 1, 1u << 18);
+    uint64_t cap = h->want_cap ? h->want_cap : std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(n + 1, 1u << 16));
     cap = std::max<uint64_t>(64, std::min<uint64_t>(cap, n + 1));
-    if (!(h->scratch_slots >= slots && h->scratch_cap == cap)) {
-        // budget: at most 60% of what is free (plus what we already hold)
+    if (!(s.slots >= slots && s.cap == cap)) {
+        // budget: at most 30% of what is free (plus what this set already holds) -- there are two sets
+        size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
-        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots = slots / 2 / qpw * qpw;
+        const uint64_t held = (uint64_t)s.slots * (s.cap * 20 + bm_bytes);
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.3);
+        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots /= 2;
         while (cap > 4096 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) cap /= 2;
-        ensure_scratch(h, slots, cap);
-    } else {
-        slots = std::min(slots, h->scratch_slots);
     }
-    if (!h->ev0) { HIP_CHECK(hipEventCreate(&h->ev0)); HIP_CHECK(hipEventCreate(&h->ev1)); }
+    ensure_scratch(h, s, slots, cap, st);
+    slots = std::min(slots, s.slots);
+    s.run_slots = slots;
+    s.nq = nq;
     // closest-entry-first launch order (device_encode.h) when the batch outnumbers the slots
     const uint32_t* d_order = nullptr;
     if (nq > slots && ordered) {
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, h->d_entry_dist.p, nq, h->d_order.p);
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, s.d_entry_dist.p, nq, s.d_order.p);
         HIP_CHECK(hipGetLastError());
-        d_order = h->d_order.p;
+        d_order = s.d_order.p;
     }
-    HIP_CHECK(hipEventRecord(h->ev0, st));
-    launch_search(h, nq, k, d_ids, d_dist, d_order, slots, cap, st, false);
-    HIP_CHECK(hipEventRecord(h->ev1, st));
-    // the statistics block (pinned host copy) says whether any query overflowed its scratch
-    HIP_CHECK(hipMemcpyAsync(h->pin_stats, h->d_stats.p, 128, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    float ms = 0.0f;
-    HIP_CHECK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    unsigned long long stats[16];
-    std::memcpy(stats, h->pin_stats, 128);
-    h->last_nq = nq;
-    std::vector<uint32_t> todo;
-    if (stats[5] != 0) {
-        std::vector<uint32_t> status(nq);
-        HIP_CHECK(hipMemcpy(status.data(), h->d_status.p, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < nq; ++i)
-            if ((status[i] & 0xFFu) != kStatusOk) todo.push_back(i);
-    }
-    if (!todo.empty()) {
-        // exact re-run of the overflowed queries with full-capacity scratch
-        const uint64_t full = n + 1;
-        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t held = (uint64_t)h->scratch_slots * (h->scratch_cap * 16 + bm_bytes);
-        uint64_t per = full * 20 + bm_bytes;
-        uint32_t s2 = (uint32_t)std::max<uint64_t>(
-            1, std::min<uint64_t>(todo.size(), (uint64_t)((free_b + held) * 0.6) / per));
-        h->d_bitmaps.release(); h->d_logids.release(); h->d_beam.release();
-        h->scratch_slots = 0; h->scratch_cap = 0;
-        s2 = (s2 + qpw - 1) / qpw * qpw;
-        ensure_scratch(h, s2, full);
-        h->d_todo.alloc(todo.size());
-        HIP_CHECK(hipMemcpyAsync(h->d_todo.p, todo.data(), todo.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipEventRecord(h->ev0, st));
-        launch_search(h, (uint32_t)todo.size(), k, d_ids, d_dist, h->d_todo.p, s2, full, st, true);
-        HIP_CHECK(hipEventRecord(h->ev1, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        float ms2 = 0.0f;
-        HIP_CHECK(hipEventElapsedTime(&ms2, h->ev0, h->ev1));
-        ms += ms2;
-    }
-    if (!todo.empty()) HIP_CHECK(hipMemcpy(stats, h->d_stats.p, 128, hipMemcpyDeviceToHost));
-#ifdef CPH_PHASE_TIMERS
-    fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
-            stats[8], stats[9], stats[10], stats[11], stats[12], stats[13], stats[14], stats[15]);
-#endif
-    if (getenv("CPH_DEBUG_STATS")) fprintf(stderr, "[stats] expansions=%llu with_no_new_neighbour=%llu\n", stats[0], stats[7]);
-    for (int i = 0; i < 6; ++i) h->last_stats[i] = stats[i];
-    h->last_stats[5] = todo.size();
-    h->last_stats[6] = (uint64_t)(ms * 1000.0);
-    h->last_stats[7] = ((uint64_t)slots << 32) | (uint32_t)std::min<uint64_t>(cap, 0xFFFFFFFFu);
+    HIP_CHECK(hipEventRecord(s.ev0, st));
+    launch_search(h, s, nq, k, d_ids, d_dist, d_order, false, st);
+    if (s.cap < n + 1) launch_search(h, s, nq, k, d_ids, d_dist, nullptr, true, st);
+    HIP_CHECK(hipEventRecord(s.ev1, st));
+    // the statistics block lands in pinned host memory; it is only read when somebody asks
+    HIP_CHECK(hipMemcpyAsync(s.pin_stats, s.d_stats.p, kStatWords * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(s.ev_done, st));
+    s.used = true;
+    h->last_search = (int)(&s - h->sets);
+}
+
+hipStream_t own_stream(cph_index* h) {
+    if (!h->own_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    return h->own_stream;
 }
 
 }  // namespace
@@ -506,10 +549,7 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         h->device = device;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
-        if (const char* e = getenv("CPH_SEARCH_KERNEL")) { int v = atoi(e); h->kernel_variant = (v == 2 || v == 4) ? v : 1; }
         if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
-        if (h->kernel_variant == 4) h->waves_per_cu = 4 * CPH_SEARCH4_WAVES_PER_SIMD;
-        if (h->kernel_variant == 2) h->waves_per_cu = 4 * CPH_SEARCH2_WAVES_PER_SIMD;
         if (const char* e = getenv("CPH_WAVES_PER_CU")) { h->waves_per_cu = (uint32_t)std::max(1, atoi(e)); h->waves_from_env = true; }
         *out = h;
     });
@@ -519,9 +559,14 @@ int cph_destroy(cph_index* h) {
     return guarded([&] {
         if (!h) return;
         (void)hipSetDevice(h->device);
-        if (h->ev0) (void)hipEventDestroy(h->ev0);
-        if (h->ev1) (void)hipEventDestroy(h->ev1);
-        if (h->pin_stats) (void)hipHostFree(h->pin_stats);
+        for (auto& s : h->sets) {
+            if (s.used && s.ev_done) (void)hipEventSynchronize(s.ev_done);
+            if (s.ev0) (void)hipEventDestroy(s.ev0);
+            if (s.ev1) (void)hipEventDestroy(s.ev1);
+            if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+            if (s.pin_stats) (void)hipHostFree(s.pin_stats);
+        }
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
         delete h;
     });
 }
@@ -563,9 +608,11 @@ int cph_build(cph_index* h, const float* vectors, uint64_t n) {
         if (n == 0) throw InvalidArg("build requires at least one vector.");
         if (!vectors) throw InvalidArg("null vectors");
         h->use_device();
+        quiesce(h);
         h->host = HostIndex();
         h->finalized = false;
         h->d_blocks.release(); h->d_raw.release(); h->d_norm.release();
+        for (auto& s : h->sets) release_scratch(s);
         h->pending.assign(vectors, vectors + n * h->dim);
         h->pending_n = n;
         h->needs_build = true;
@@ -632,10 +679,26 @@ int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity) 
     });
 }
 
-int cph_last_search_stats(cph_index* h, uint64_t out[8]) {
+int cph_last_search_stats(cph_index* h, uint64_t out[12]) {
     return guarded([&] {
+        if (!h || !out) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
-        for (int i = 0; i < 8; ++i) out[i] = h->last_stats[i];
+        for (int i = 0; i < 12; ++i) out[i] = 0;
+        if (h->last_search < 0) return;
+        BatchSet& s = h->sets[h->last_search];
+        h->use_device();
+        HIP_CHECK(hipEventSynchronize(s.ev_done));
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
+        for (int i = 0; i < 6; ++i) out[i] = s.pin_stats[i];
+        out[6] = (uint64_t)(ms * 1000.0);
+        out[7] = s.pin_stats[7];
+        out[8] = s.run_slots;
+        out[9] = s.cap;
+#ifdef CPH_PHASE_TIMERS
+        fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
+                s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);
+#endif
     });
 }
 
@@ -643,10 +706,22 @@ int cph_last_query_expansions(cph_index* h, uint32_t* out, uint64_t n) {
     return guarded([&] {
         if (!h || !out) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
-        if (n != h->last_nq) throw InvalidArg("n must equal the size of the last batch");
+        if (h->last_search < 0 || n != h->sets[h->last_search].nq)
+            throw InvalidArg("n must equal the size of the last batch");
+        BatchSet& s = h->sets[h->last_search];
         h->use_device();
-        HIP_CHECK(hipMemcpy(out, h->d_status.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipEventSynchronize(s.ev_done));
+        HIP_CHECK(hipMemcpy(out, s.d_status.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n; ++i) out[i] >>= 8;
+    });
+}
+
+int cph_synchronize(cph_index* h) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->use_device();
+        quiesce(h);
     });
 }
 
@@ -678,14 +753,21 @@ int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k,
             return;
         }
         if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
+        if (!queries || !ids || !dist) throw InvalidArg("null argument");
         h->use_device();
-        hipStream_t st = nullptr;
-        stage_queries(h, upload_queries(h, queries, n, st), n, st);
-        h->d_ids.alloc(n * k);
-        h->d_dist.alloc(n * k);
-        run_search(h, (uint32_t)n, (uint32_t)k, h->d_ids.p, h->d_dist.p, st);
-        HIP_CHECK(hipMemcpy(ids, h->d_ids.p, n * k * 8, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(dist, h->d_dist.p, n * k * 4, hipMemcpyDeviceToHost));
+        hipStream_t st = own_stream(h);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, upload_queries(h, s, queries, n, st), n, st);
+        if (s.d_ids.n < n * k) {
+            if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+            s.d_ids.alloc(n * k);
+            s.d_dist.alloc(n * k);
+        }
+        enqueue_search(h, s, (uint32_t)n, (uint32_t)k, s.d_ids.p, s.d_dist.p, st);
+        HIP_CHECK(hipMemcpyAsync(ids, s.d_ids.p, n * k * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(dist, s.d_dist.p, n * k * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(s.ev_done, st));
+        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 
@@ -697,10 +779,12 @@ int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, ui
         require_finalized(h);
         if (n == 0 || k == 0) return;
         if (n > 0xFFFFFFFFull || k > 0xFFFFFFFFull) throw InvalidArg("batch too large");
+        if (!d_queries || !d_ids || !d_dist) throw InvalidArg("null argument");
         h->use_device();
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        stage_queries(h, d_queries, n, st);
-        run_search(h, (uint32_t)n, (uint32_t)k, d_ids, d_dist, st);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, d_queries, n, st);
+        enqueue_search(h, s, (uint32_t)n, (uint32_t)k, d_ids, d_dist, st);
     });
 }
 
@@ -713,17 +797,22 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
         const uint64_t kk = std::max<uint64_t>(k, 1);  // api/hnsw_index.hpp:187
         if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
         h->use_device();
-        hipStream_t st = nullptr;
-        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
-        h->d_ids.alloc(kk);
-        h->d_dist.alloc(kk);
-        run_search(h, 1, (uint32_t)kk, h->d_ids.p, h->d_dist.p, st);
+        hipStream_t st = own_stream(h);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, upload_queries(h, s, query, 1, st), 1, st);
+        if (s.d_ids.n < kk) {
+            if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+            s.d_ids.alloc(kk);
+            s.d_dist.alloc(kk);
+        }
+        enqueue_search(h, s, 1, (uint32_t)kk, s.d_ids.p, s.d_dist.p, st);
+        HIP_CHECK(hipStreamSynchronize(st));
         uint32_t cnt = 0;
-        HIP_CHECK(hipMemcpy(&cnt, h->d_count.p, 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&cnt, s.d_count.p, 4, hipMemcpyDeviceToHost));
         // the reference returns every result it found (<= max(k,1)); the caller's buffers
         // hold max(k,1) entries
-        HIP_CHECK(hipMemcpy(ids, h->d_ids.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(dist, h->d_dist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(ids, s.d_ids.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dist, s.d_dist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
         *m = cnt;
     });
 }
@@ -734,13 +823,17 @@ int cph_encode_query(cph_index* h, const float* query, uint8_t* lut, float* coef
         std::lock_guard<std::mutex> lk(h->mu);
         require_finalized(h);  // the device encoder lives with the loaded index
         h->use_device();
-        hipStream_t st = nullptr;
-        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
+        hipStream_t st = own_stream(h);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, upload_queries(h, s, query, 1, st), 1, st);
+        HIP_CHECK(hipEventRecord(s.ev_done, st));
+        s.used = true;
+        HIP_CHECK(hipStreamSynchronize(st));
         const uint32_t D = h->D, PW = h->L.PW;
         std::vector<uint32_t> masks(PW * 4);
         QueryHeader hd;
-        HIP_CHECK(hipMemcpy(masks.data(), h->d_qmasks.p, PW * 16, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(&hd, h->d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(masks.data(), s.d_qmasks.p, PW * 16, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&hd, s.d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
         std::vector<uint8_t> qu(D);
         for (uint32_t d = 0; d < D; ++d) {
             uint8_t u = 0;
@@ -757,10 +850,14 @@ int cph_entry_point(cph_index* h, const float* query, uint32_t* entry) {
         std::lock_guard<std::mutex> lk(h->mu);
         require_finalized(h);
         h->use_device();
-        hipStream_t st = nullptr;
-        stage_queries(h, upload_queries(h, query, 1, st), 1, st);
+        hipStream_t st = own_stream(h);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, upload_queries(h, s, query, 1, st), 1, st);
+        HIP_CHECK(hipEventRecord(s.ev_done, st));
+        s.used = true;
+        HIP_CHECK(hipStreamSynchronize(st));
         QueryHeader hd;
-        HIP_CHECK(hipMemcpy(&hd, h->d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(&hd, s.d_qhdr.p, sizeof(hd), hipMemcpyDeviceToHost));
         *entry = hd.entry;
     });
 }

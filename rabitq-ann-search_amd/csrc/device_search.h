@@ -45,8 +45,9 @@ struct SearchArgs {
     const float* queries;   // [nq][D] zero-padded
     const uint4* qmasks;    // [nq][PW]
     const QueryHeader* qhdr;
-    const uint32_t* todo;   // optional: query indices to run (re-run list), else 0..nq-1
+    const uint32_t* todo;   // optional: query indices to run (launch order / re-run list), else 0..nq-1
     uint32_t nq;
+    const uint32_t* nq_dev; // optional: the batch size lives in device memory (the overflow re-run's list length)
     uint32_t k;
     SearchConsts sc;
     // work queue + per-slot scratch
@@ -61,7 +62,11 @@ struct SearchArgs {
     float* out_dist;        // [nq][k]
     uint32_t* out_count;    // [nq]
     uint32_t* status;       // [nq]
-    unsigned long long* stats;  // [8]
+    unsigned long long* stats;  // [16]
+    // queries whose beam or id log outgrew `cap` are appended here and answered by the full-capacity
+    // re-run launch that follows on the same stream (no host round trip)
+    uint32_t* redo;         // [nq] or null
+    uint32_t* redo_count;
 };
 
 // ---- libstdc++-compatible binary heaps ------------------------------------------------
@@ -276,6 +281,10 @@ __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint
 // neighbour-id wait behind the whole block.  The compiler therefore does not know about these
 // loads; loads retire in order, so its own counted waits stay correct (merely conservative),
 // and the one place that reads a DMA target waits explicitly.  LDS destination = M0 + lane * size.
+// M0 is written inside the asm without appearing in the clobber list: it is a reserved register for
+// LLVM's AMDGPU backend (clang warns that "m0" in a clobber list is not honoured); the backend never
+// keeps a value live in it across other instructions -- every instruction that reads M0 gets its own
+// copy glued directly in front of it -- so overwriting it here cannot be observed.
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void*)p);
@@ -337,12 +346,13 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     // (Switching to it when a larger batch starts to drain was tried: any way of telling thousands of
     // running waves that the queue is empty -- polling the counter or a flag word -- cost far more than
     // the prefetch gains in the drain phase.)
-    const bool lat = a.nq <= gridDim.x;
+    const uint32_t nq = a.nq_dev ? *a.nq_dev : a.nq;
+    const bool lat = nq <= gridDim.x;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.counter, 1u);
         t = bcast_u32(t);
-        if (t >= a.nq) break;
+        if (t >= nq) break;
         const uint32_t qi = a.todo ? a.todo[t] : t;
 
         for (uint32_t w = lane; w < PW; w += 64) qm[w] = a.qmasks[(size_t)qi * PW + w];
@@ -746,7 +756,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);
 #endif
-            if (overflow) atomicAdd(&a.stats[5], 1ull);
+            if (overflow) {
+                atomicAdd(&a.stats[5], 1ull);
+                if (a.redo) a.redo[atomicAdd(a.redo_count, 1u)] = qi;
+            }
         }
         // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --
         __syncthreads();
