@@ -71,11 +71,14 @@ int cph_is_finalized(cph_index* h, int* flag);
  * bit-level, parity with the reference's builder (which depends on its thread count). */
 int cph_build(cph_index* h, const float* vectors, uint64_t n);
 int cph_finalize(cph_index* h);
-/* Construction hook: exact 32 nearest neighbours (squared L2, self excluded, ascending) of
- * every row of vectors[n][dim] by GPU brute force — the working lists the reference obtains
- * from NNDescent (graph/graph_refinement.hpp:455-515).  ids/dist: [n][32]. */
-int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, uint32_t* ids,
-                       float* dist);
+/* Construction / ground-truth hook: exact 32 nearest neighbours (squared L2, ascending) by brute
+ * force on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32).  queries == NULL: of every row of
+ * vectors[n][dim] against the other rows (self excluded) -- the working lists the reference obtains
+ * from NNDescent (graph/graph_refinement.hpp:455-515; distances core/memory.hpp:65-79), ids/dist
+ * [n][32].  queries != NULL: of queries[nq][dim] against vectors[n][dim], ids/dist [nq][32].  Rows
+ * with fewer than 32 candidates are padded with 0xFFFFFFFF / FLT_MAX. */
+int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, const float* queries,
+                       uint64_t nq, uint32_t* ids, float* dist);
 
 /* ---- search ---------------------------------------------------------------------- */
 /* queries: host, row-major [n][dim] float32.  ids/dist: host, [n][k], rows shorter than k

@@ -19,7 +19,8 @@ SYMBOLS = {
     "cph_is_finalized": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cph_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "cph_finalize": (C.c_int, [C.c_void_p]),
-    "cph_knn_bruteforce": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "cph_knn_bruteforce": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                     C.c_void_p, C.c_void_p]),
     "cph_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cph_search_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),

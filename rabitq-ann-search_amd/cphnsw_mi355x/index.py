@@ -216,14 +216,21 @@ class CPIndex:
         return out
 
 
-def knn_bruteforce(vectors, device=None):
-    """Exact 32-NN graph (ids uint32 [n,32], squared distances float32 [n,32]) on the GPU."""
+def knn_bruteforce(vectors, queries=None, device=None):
+    """Exact 32 nearest neighbours on the GPU's matrix cores: ids uint32, squared distances float32.
+    queries=None: every row of `vectors` against the others (self excluded), shape [n, 32];
+    else `queries` against `vectors`, shape [nq, 32]."""
     v = _as_f32(vectors)
     n, dim = v.shape
-    ids = np.zeros((n, 32), np.uint32)
-    dist = np.zeros((n, 32), np.float32)
+    q = None if queries is None else _as_f32(queries)
+    if q is not None and (q.ndim != 2 or q.shape[1] != dim):
+        raise ValueError("queries must be a (nq, dim) array")
+    rows = n if q is None else q.shape[0]
+    ids = np.zeros((rows, 32), np.uint32)
+    dist = np.zeros((rows, 32), np.float32)
     dev = _default_device() if device is None else int(device)
-    _lib.check(_lib.lib().cph_knn_bruteforce(dev, v.ctypes.data, n, dim, ids.ctypes.data, dist.ctypes.data))
+    _lib.check(_lib.lib().cph_knn_bruteforce(dev, v.ctypes.data, n, dim, None if q is None else q.ctypes.data,
+                                             0 if q is None else q.shape[0], ids.ctypes.data, dist.ctypes.data))
     return ids, dist
 
 

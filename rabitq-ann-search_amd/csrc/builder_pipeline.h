@@ -174,33 +174,68 @@ struct UpperBuilder {  // api/hnsw_index.hpp:476-716 on the pre-reorder ids
     }
 };
 
-// Exact kKnnK-NN of every row of x[n][D] (self excluded), ascending by distance.
-inline void gpu_knn(const float* x, const float* norm_sq, size_t n, size_t D, int num_cus, uint32_t* out_ids,
-                    float* out_dist) {
-    float *d_x = nullptr, *d_norm = nullptr, *d_od = nullptr;
-    uint32_t* d_oi = nullptr;
-    auto ck = [](hipError_t e) {
-        if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in kNN build: ") + hipGetErrorString(e));
-    };
-    ck(hipMalloc((void**)&d_x, n * D * 4));
-    ck(hipMalloc((void**)&d_norm, n * 4));
-    ck(hipMalloc((void**)&d_oi, n * kKnnK * 4));
-    ck(hipMalloc((void**)&d_od, n * kKnnK * 4));
-    ck(hipMemcpy(d_x, x, n * D * 4, hipMemcpyHostToDevice));
-    ck(hipMemcpy(d_norm, norm_sq, n * 4, hipMemcpyHostToDevice));
-    // several launches so that no single kernel runs for minutes
-    const uint32_t rows_per_launch = (uint32_t)std::max<size_t>(64, ((size_t)num_cus * 2 * 64 * 8));
-    for (size_t rb = 0; rb < n; rb += rows_per_launch) {
-        KnnArgs a{d_x, d_norm, (uint32_t)n, (uint32_t)D, (uint32_t)rb,
-                  (uint32_t)std::min<size_t>(n, rb + rows_per_launch), d_oi, d_od};
-        const uint32_t grid = (a.row_end - a.row_begin + 63) / 64;
-        hipLaunchKernelGGL(knn_bruteforce_kernel, dim3(grid), dim3(256), 0, nullptr, a);
-        ck(hipGetLastError());
-        ck(hipDeviceSynchronize());
+// RAII device buffer for the construction kernels.
+template <class T>
+struct BuildBuf {
+    T* p = nullptr;
+    explicit BuildBuf(size_t count) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            if (e == hipErrorOutOfMemory) throw std::bad_alloc();
+            throw std::runtime_error(std::string("HIP error in index construction: ") + hipGetErrorString(e));
+        }
     }
-    ck(hipMemcpy(out_ids, d_oi, n * kKnnK * 4, hipMemcpyDeviceToHost));
-    ck(hipMemcpy(out_dist, d_od, n * kKnnK * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(d_x); (void)hipFree(d_norm); (void)hipFree(d_oi); (void)hipFree(d_od);
+    ~BuildBuf() { if (p) (void)hipFree(p); }
+    BuildBuf(const BuildBuf&) = delete;
+    BuildBuf& operator=(const BuildBuf&) = delete;
+};
+inline void build_ck(hipError_t e) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in index construction: ") + hipGetErrorString(e));
+}
+
+// Exact 32-NN of query rows [0, nq) of d_q against base rows d_b, all device pointers; ascending by
+// distance.  Launched in slices of row blocks so that no single launch runs for minutes.
+// D must be a multiple of 32 (the kernel's K stage); narrower rows are zero-padded by the callers.
+inline void knn_device(const float* d_q, const float* d_qnorm, size_t nq, const float* d_b, const float* d_bnorm,
+                       size_t nb, size_t D, bool exclude_self, int num_cus, uint32_t* d_ids, float* d_dist) {
+    if (D % kKnnKC != 0 || nq == 0 || nb == 0) throw std::invalid_argument("knn_device: D must be a multiple of 32");
+    const uint32_t rows_per_launch = (uint32_t)num_cus * 8u * kKnnTile;
+    for (size_t rb = 0; rb < nq; rb += rows_per_launch) {
+        KnnArgs a{d_q, d_b, d_bnorm, d_qnorm, (uint32_t)nq, (uint32_t)nb, (uint32_t)D, (uint32_t)rb,
+                  (uint32_t)std::min<size_t>(nq, rb + rows_per_launch), exclude_self ? 1u : 0u, d_ids, d_dist};
+        const uint32_t grid = (a.row_end - a.row_begin + kKnnTile - 1) / kKnnTile;
+        hipLaunchKernelGGL(knn_mfma_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+        build_ck(hipGetLastError());
+        build_ck(hipDeviceSynchronize());
+    }
+}
+
+// Host-pointer convenience: x[n][D] against itself (self excluded) or q[nq][D] against x[n][D].
+inline void gpu_knn(const float* q, const float* qnorm, size_t nq, const float* x, const float* norm_sq, size_t n,
+                    size_t D, int num_cus, uint32_t* out_ids, float* out_dist) {
+    const bool self = (q == nullptr);
+    const size_t Dk = (D + kKnnKC - 1) / kKnnKC * kKnnKC;      // D = 16 -> 32: zero columns
+    BuildBuf<float> d_x(n * Dk), d_norm(n), d_od((self ? n : nq) * kKnnK);
+    BuildBuf<uint32_t> d_oi((self ? n : nq) * kKnnK);
+    auto upload = [&](float* dst, const float* src, size_t rows) {
+        if (Dk == D) { build_ck(hipMemcpy(dst, src, rows * D * 4, hipMemcpyHostToDevice)); return; }
+        build_ck(hipMemset(dst, 0, rows * Dk * 4));
+        build_ck(hipMemcpy2D(dst, Dk * 4, src, D * 4, D * 4, rows, hipMemcpyHostToDevice));
+    };
+    upload(d_x.p, x, n);
+    build_ck(hipMemcpy(d_norm.p, norm_sq, n * 4, hipMemcpyHostToDevice));
+    if (self) {
+        knn_device(d_x.p, d_norm.p, n, d_x.p, d_norm.p, n, Dk, true, num_cus, d_oi.p, d_od.p);
+        nq = n;
+    } else {
+        BuildBuf<float> d_q(nq * Dk), d_qn(nq);
+        upload(d_q.p, q, nq);
+        build_ck(hipMemcpy(d_qn.p, qnorm, nq * 4, hipMemcpyHostToDevice));
+        knn_device(d_q.p, d_qn.p, nq, d_x.p, d_norm.p, n, Dk, false, num_cus, d_oi.p, d_od.p);
+    }
+    build_ck(hipMemcpy(out_ids, d_oi.p, nq * kKnnK * 4, hipMemcpyDeviceToHost));
+    build_ck(hipMemcpy(out_dist, d_od.p, nq * kKnnK * 4, hipMemcpyDeviceToHost));
 }
 
 // The whole finalize.  `vecs` = n x dim input rows.  Fills `hi` (reference-layout host index).
@@ -294,7 +329,7 @@ inline void finalize_index(HostIndex& hi, const float* vecs, size_t n, size_t di
     // ---- exact 32-NN working lists on the GPU (replaces NNDescent) ------------------------
     std::vector<uint32_t> knn_ids(n * kKnnK);
     std::vector<float> knn_d(n * kKnnK);
-    gpu_knn(raw.data(), norm_sq.data(), n, D, num_cus, knn_ids.data(), knn_d.data());
+    gpu_knn(nullptr, nullptr, 0, raw.data(), norm_sq.data(), n, D, num_cus, knn_ids.data(), knn_d.data());
     note("GPU exact 32-NN");
 
     auto vec = [&](uint32_t i) { return &raw[(size_t)i * D]; };

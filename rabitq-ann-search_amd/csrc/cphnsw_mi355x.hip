@@ -640,23 +640,33 @@ int cph_finalize(cph_index* h) {
     });
 }
 
-int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, uint32_t* ids,
-                       float* dist) {
+int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, const float* queries,
+                       uint64_t nq, uint32_t* ids, float* dist) {
     return guarded([&] {
         if (!vectors || !ids || !dist || n == 0 || dim == 0) throw InvalidArg("bad arguments");
+        if (n >= 0xFFFFFFFFull || nq >= 0xFFFFFFFFull) throw InvalidArg("too many rows");
         HIP_CHECK(hipSetDevice(device));
         const size_t D = std::max<size_t>(16, next_pow2(dim));
-        std::vector<float> x(n * D, 0.0f), nrm(n);
-        for (uint64_t i = 0; i < n; ++i) {
-            std::memcpy(&x[i * D], vectors + i * dim, dim * 4);
-            float s = 0.0f;
-            for (uint64_t j = 0; j < dim; ++j) s = std::fmaf(x[i * D + j], x[i * D + j], s);
-            nrm[i] = s;
-        }
+        auto pad = [&](const float* src, uint64_t rows, std::vector<float>& x, std::vector<float>& nrm) {
+            x.assign(rows * D, 0.0f);
+            nrm.resize(rows);
+            parallel_for(rows, 1024, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    std::memcpy(&x[i * D], src + i * dim, dim * 4);
+                    float s = 0.0f;
+                    for (uint64_t j = 0; j < dim; ++j) s = std::fmaf(x[i * D + j], x[i * D + j], s);
+                    nrm[i] = s;
+                }
+            });
+        };
+        std::vector<float> x, nrm, q, qn;
+        pad(vectors, n, x, nrm);
+        if (queries) pad(queries, nq, q, qn);
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
-        build::gpu_knn(x.data(), nrm.data(), n, D, cus, ids, dist);
+        build::gpu_knn(queries ? q.data() : nullptr, queries ? qn.data() : nullptr, nq, x.data(), nrm.data(), n, D,
+                       cus, ids, dist);
     });
 }
 

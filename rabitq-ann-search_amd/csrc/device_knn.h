@@ -1,13 +1,35 @@
-// device_knn.h — exact k-nearest-neighbour graph by tiled brute force (index construction).
+// device_knn.h — exact k-nearest-neighbour lists by brute force on the matrix cores (index
+// construction and the recall ground truth).
 //
-// Replaces the reference's CPU NNDescent (graph/graph_refinement.hpp:71-263, 455-515), whose
-// product is a working list of the R=32 nearest neighbours per node.  On MI355X the exact
-// answer is cheaper than the approximation: n² · D FMAs in fp32 (2.6e14 flop at n = 1M,
-// D = 128) with a threshold-filtered top-K kept in LDS, so nothing but the K results per node
-// is ever written to HBM.
+// Replaces the reference's CPU NNDescent (graph/graph_refinement.hpp:71-263, 455-515), whose product
+// is a working list of the R = 32 nearest neighbours per node, and its distance routine
+// l2_distance_simd (core/memory.hpp:65-79).  On MI355X the exact answer is cheaper than the
+// approximation: the n_q x n_b x D contraction runs on v_mfma_f32_32x32x2_f32 (f32 in, f32
+// accumulate: bit-for-bit a k-ordered fmaf chain, so nothing is lost against a VALU kernel) and a
+// threshold-filtered top-32 per query row lives in LDS, so nothing but the 32 results per row is
+// ever written to HBM.
 //
-// One workgroup = 64 query rows x all base rows, 64x64 distance tiles, 4x4 register micro-tile
-// per thread, K dimension staged through LDS in chunks of 32.  dist = |q|² + |b|² − 2 q·b.
+// Geometry.  One workgroup (4 waves, one per SIMD) = 128 query rows against every base row, in
+// 128-column tiles; the K dimension is staged through LDS in chunks of 32 floats with the next
+// chunk's global loads in flight during the current chunk's 64 MFMAs per wave (register prefetch).
+// Wave w owns rows 32w..32w+31 of the tile and computes all 128 columns for them (1 x 4 MFMA tiles of
+// 32 x 32), so the per-row candidate lists are touched by one wave only and the selection needs no
+// workgroup barrier.
+//
+// Ranking key.  The accumulators start at -|b|^2 / 2, so a finished accumulator holds
+//     s = q.b - |b|^2 / 2,        |q - b|^2 = |q|^2 - 2 s,
+// and "nearer" is "larger s" with a per-row constant removed: the filter is ONE v_cmp per element
+// against the row's threshold (kept in registers).  Passing elements are appended to the row's
+// 64-entry LDS list; only when an append would not fit is the list sorted and cut back to its best 32 by
+// rank computation (every lane holds one entry and counts the entries that beat it, broadcast through
+// v_readlane), which also yields the new threshold: the 32nd best key seen so far.  Between two sorts the
+// threshold is stale by at most 32 appends, which costs a few extra appends and never a wrong result.
+//
+// LDS operand image: row-major [128][32 + 4] floats.  Lane (h = lane >> 5, c = lane & 31) reads
+// its row's k = 8j + 4h .. 8j + 4h + 3 with one ds_read_b128 and feeds the four values to four
+// consecutive MFMAs; A and B use the same k for the same (lane half, step), which is all the
+// instruction needs -- the order in which k is summed is irrelevant to an exact-kNN list.  The 36-float
+// stride makes the 16 rows of each ds_read_b128 lane group land on 16 distinct 4-bank spans.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -15,130 +37,210 @@
 
 namespace cph {
 
-constexpr int kKnnK = 32;       // neighbours kept per row (R)
-constexpr int kKnnCap = 96;     // per-row candidate buffer (K + up to 64 new per tile)
+constexpr int kKnnK = 32;        // neighbours kept per row (R)
+constexpr int kKnnTile = 128;    // rows per workgroup, columns per tile
+constexpr int kKnnKC = 32;       // floats of K per LDS stage
+constexpr int kKnnLd = kKnnKC + 4;
+constexpr int kKnnCap = 64;      // per-row candidate list: one entry per lane when it is sorted
 
 struct KnnArgs {
-    const float* x;        // [n][D]
-    const float* norm;     // [n] squared norms (fp32)
-    uint32_t n, D;
+    const float* q;        // [nq][D] query rows (zero padded to D)
+    const float* b;        // [nb][D] base rows
+    const float* bnorm;    // [nb] squared norms of the base rows
+    const float* qnorm;    // [nq]
+    uint32_t nq, nb, D;
     uint32_t row_begin, row_end;   // query rows handled by this launch
-    uint32_t* out_ids;     // [n][K] ascending by distance
-    float* out_dist;       // [n][K]
+    uint32_t exclude_self;         // q == b: row i never lists column i
+    uint32_t* out_ids;     // [nq][32] ascending by distance, 0xFFFFFFFF padded
+    float* out_dist;       // [nq][32] squared L2, FLT_MAX padded
 };
 
-__global__ __launch_bounds__(256) void knn_bruteforce_kernel(KnnArgs a) {
-    __shared__ float Qs[32][64 + 4];     // [k][row]  (transposed: conflict-free column reads)
-    __shared__ float Bs[32][64 + 4];     // [k][col]
-    __shared__ float cand_d[64][kKnnCap];
-    __shared__ uint32_t cand_i[64][kKnnCap];
-    __shared__ uint32_t cnt[64];
-    __shared__ float tau[64];
+typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers
+
+// Sorts row r's list (c <= 64 entries, one per lane) by (key descending, id ascending), keeps the best
+// 32 and publishes the new threshold.  Whole wave; the row belongs to this wave.  Every lane's entry is
+// broadcast through the scalar registers (v_readlane) and compared on all lanes at once: a lane's rank is
+// the number of entries that beat its own -- no LDS round trips, no data-dependent shuffles.
+__device__ __attribute__((noinline)) void knn_compact(float* cs, uint32_t* ci, uint32_t* cnt, float* sig, int r, int lane) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[r]);
+    const float NEG = -__builtin_inff();
+    const float s = (uint32_t)lane < c ? cs[r * kKnnCap + lane] : NEG;
+    const uint32_t id = (uint32_t)lane < c ? ci[r * kKnnCap + lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int j = 0; j < kKnnCap; ++j) {
+        const float sj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(s), j));
+        const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
+        rank += (sj > s || (sj == s && ij < id)) ? 1u : 0u;
+    }
+    if ((uint32_t)lane < c && rank < (uint32_t)kKnnK) {
+        cs[r * kKnnCap + rank] = s;
+        ci[r * kKnnCap + rank] = id;
+        if (rank == (uint32_t)kKnnK - 1) sig[r] = s;
+    }
+    if (lane == 0) cnt[r] = c < (uint32_t)kKnnK ? c : (uint32_t)kKnnK;
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
+    __shared__ __align__(16) float Qs[2][kKnnTile * kKnnLd];     // double-buffered operand images
+    __shared__ __align__(16) float Bs[2][kKnnTile * kKnnLd];
+    __shared__ float cs[kKnnTile * kKnnCap];
+    __shared__ uint32_t ci[kKnnTile * kKnnCap];
+    __shared__ uint32_t cnt[kKnnTile];
+    __shared__ float sig[kKnnTile];
 
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;         // 16 x 16 threads, 4x4 outputs each
-    const uint32_t row0 = a.row_begin + blockIdx.x * 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int h = lane >> 5, c = lane & 31;
+    const uint32_t row0 = a.row_begin + blockIdx.x * kKnnTile;
     if (row0 >= a.row_end) return;
-    if (tid < 64) { cnt[tid] = 0; tau[tid] = 3.402823466e+38f; }
-    __syncthreads();
+    const float NEG_INF = -__builtin_inff();
+    if (tid < kKnnTile) { cnt[tid] = 0; sig[tid] = NEG_INF; }
 
-    for (uint32_t col0 = 0; col0 < a.n; col0 += 64) {
-        float acc[4][4];
+    const uint32_t D = a.D;                       // multiple of kKnnKC (the host pads)
+    const uint32_t nchunk = D / kKnnKC;
+    const uint32_t ntile = (a.nb + kKnnTile - 1) / kKnnTile;
+
+    // Staging: 4 x 16 B per operand per thread and chunk; element e = tid + 256 i -> row e >> 3, float4
+    // e & 7 of the chunk.  Rows past the end are clamped to the last row instead of predicated (no
+    // branches between the MFMAs): a clamped query row computes keys nobody reads, a clamped base row
+    // belongs to a column whose accumulator starts at -inf and therefore never passes the filter.
+    const uint32_t srow = tid >> 3, skq = (tid & 7) * 4;
+    const float* qsrc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
-        for (uint32_t k0 = 0; k0 < a.D; k0 += 32) {
-            // stage 64 rows x 32 k of Q and B (transposed into [k][row])
-            for (int e = tid; e < 64 * 32; e += 256) {
-                const int r = e >> 5, k = e & 31;
-                const uint32_t qr = row0 + r, br = col0 + r;
-                Qs[k][r] = (qr < a.n && k0 + k < a.D) ? a.x[(size_t)qr * a.D + k0 + k] : 0.0f;
-                Bs[k][r] = (br < a.n && k0 + k < a.D) ? a.x[(size_t)br * a.D + k0 + k] : 0.0f;
-            }
-            __syncthreads();
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                float q[4], b[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q[i] = Qs[k][ty * 4 + i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(q[i], b[j], acc[i][j]);
-            }
-            __syncthreads();
-        }
-        // threshold filter into the per-row candidate buffers
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t qr = row0 + srow + 32 * i;
+        qsrc[i] = a.q + (size_t)(qr < a.nq ? qr : a.nq - 1) * D + skq;
+    }
+    knn_f32x4 pq[4], pb[4];
+    auto fetch = [&](uint32_t tile, uint32_t ch) {
+        const uint32_t k0 = ch * kKnnKC;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = ty * 4 + i;
-            const uint32_t qr = row0 + r;
-            if (qr >= a.n || qr >= a.row_end) continue;
-            const float qn = a.norm[qr];
-            const float t = tau[r];
+            const uint32_t br = tile * kKnnTile + srow + 32 * i;
+            pq[i] = *reinterpret_cast<const knn_f32x4*>(qsrc[i] + k0);
+            pb[i] = *reinterpret_cast<const knn_f32x4*>(a.b + (size_t)(br < a.nb ? br : a.nb - 1) * D + skq + k0);
+        }
+    };
+    auto stage = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t bc = col0 + tx * 4 + j;
-                if (bc >= a.n || bc == qr) continue;
-                float d = (qn + a.norm[bc]) - 2.0f * acc[i][j];
-                d = d > 0.0f ? d : 0.0f;
-                if (d < t) {
-                    const uint32_t pos = atomicAdd(&cnt[r], 1u);
-                    if (pos < (uint32_t)kKnnCap) { cand_d[r][pos] = d; cand_i[r][pos] = bc; }
-                }
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<knn_f32x4*>(&Qs[buf][(srow + 32 * i) * kKnnLd + skq]) = pq[i];
+            *reinterpret_cast<knn_f32x4*>(&Bs[buf][(srow + 32 * i) * kKnnLd + skq]) = pb[i];
+        }
+    };
+
+    knn_f32x16 acc[4];
+    float sg[16];                       // thresholds of this lane's 16 rows
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sg[i] = NEG_INF;
+    const int wrow = wave * 32;         // first tile row of this wave
+
+    fetch(0, 0);
+    stage(0);
+    __syncthreads();                    // first operand image, cnt and sig are in place
+    int buf = 0;
+    for (uint32_t tile = 0; tile < ntile; ++tile)
+    for (uint32_t ch = 0; ch < nchunk; ++ch) {
+        if (ch == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t col = tile * kKnnTile + t * 32 + c;
+                const float init = col < a.nb ? -0.5f * a.bnorm[col] : NEG_INF;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = init;
             }
         }
-        __syncthreads();
-        // compaction: rows whose buffer could overflow on the next tile keep their K best
-        const int wave = tid >> 6, lane = tid & 63;
-        const bool last = col0 + 64 >= a.n;
-        for (int r = wave; r < 64; r += 4) {
-            uint32_t c = cnt[r];
-            if (c > (uint32_t)kKnnCap) c = kKnnCap;   // cannot happen: <= K + 64 by construction
-            if (!(c > (uint32_t)(kKnnCap - 64) || (last && c > 0))) continue;
-            // selection of the min(K, c) smallest by repeated wave-min extraction;
-            // entries lane and lane+64; ties broken by smaller id for determinism
-            float d0 = lane < (int)c ? cand_d[r][lane] : 3.402823466e+38f;
-            float d1 = lane + 64 < (int)c ? cand_d[r][lane + 64] : 3.402823466e+38f;
-            uint32_t i0 = lane < (int)c ? cand_i[r][lane] : 0xFFFFFFFFu;
-            uint32_t i1 = lane + 64 < (int)c ? cand_i[r][lane + 64] : 0xFFFFFFFFu;
-            const uint32_t keep = c < (uint32_t)kKnnK ? c : (uint32_t)kKnnK;
-            float kth = 0.0f;
-            for (uint32_t s = 0; s < keep; ++s) {
-                float md = d0; uint32_t mi = i0; int which = 0;
-                if (d1 < md || (d1 == md && i1 < mi)) { md = d1; mi = i1; which = 1; }
-                float bd = md; uint32_t bi = mi;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const float od = __shfl_xor(bd, o);
-                    const uint32_t oi = __shfl_xor(bi, o);
-                    if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-                }
-                if (mi == bi && md == bd) {   // this lane owns the extracted element
-                    if (which == 0) { d0 = 3.402823466e+38f; i0 = 0xFFFFFFFFu; }
-                    else { d1 = 3.402823466e+38f; i1 = 0xFFFFFFFFu; }
-                }
-                if (lane == 0) { cand_d[r][s] = bd; cand_i[r][s] = bi; }
-                kth = bd;
-                // LDS writes by lane 0 alias entries other lanes already hold in registers: safe
-            }
-            if (lane == 0) {
-                cnt[r] = keep;
-                if (keep == (uint32_t)kKnnK) tau[r] = kth;
+        // the next chunk's loads are in flight during the MFMAs below
+        // (unconditionally: behind the last chunk the last tile is fetched once more and never used)
+        const bool wrap = ch + 1 == nchunk;
+        const uint32_t ntl = wrap ? (tile + 1 < ntile ? tile + 1 : tile) : tile, nch = wrap ? 0 : ch + 1;
+        fetch(ntl, nch);
+        const float* Qb = Qs[buf];
+        const float* Bb = Bs[buf];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const knn_f32x4 av = *reinterpret_cast<const knn_f32x4*>(&Qb[(wrow + c) * kKnnLd + 8 * j + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const knn_f32x4 bv = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
             }
         }
+        // The other image was last read one chunk ago and every wave has passed a barrier since: it can
+        // be overwritten now; ONE barrier per chunk then publishes it.
+        stage(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
+        if (ch + 1 != nchunk) continue;
+
+        // ---- tile finished: filter its 4 x (32 x 32) keys against the row thresholds ----------
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= acc[t][i] > sg[i];
+            if (!__any(any)) continue;
+            const uint32_t col = tile * kKnnTile + t * 32 + c;
+            bool compacted = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rlo = wrow + (i & 3) + 8 * (i >> 2);           // C/D layout of the 32x32 MFMA:
+                const int r = rlo + 4 * h;                               // lane half h holds row rlo + 4h
+                const float s = acc[t][i];
+                bool pass = s > sg[i] && !(a.exclude_self && col == row0 + (uint32_t)r);
+                if (__ballot(pass) == 0) continue;
+                // the 32 lanes of a half share the row; the two halves take their turns (wave-uniform)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int rr = rlo + 4 * hh;
+                    bool mine = pass && h == hh;
+                    uint32_t mh = (uint32_t)(__ballot(mine) >> (32 * hh));
+                    if (mh == 0) continue;
+                    uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[rr]);
+                    if (base + __popc(mh) > (uint32_t)kKnnCap) {
+                        // the list is full: sort, keep the best 32, raise the threshold and look again
+                        knn_compact(cs, ci, cnt, sig, rr, lane);
+                        compacted = true;
+                        mine = mine && s > sig[rr];
+                        mh = (uint32_t)(__ballot(mine) >> (32 * hh));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[rr]);
+                    }
+                    if (mine) {
+                        const uint32_t pos = base + __popc(mh & ((1u << c) - 1u));
+                        cs[rr * kKnnCap + pos] = s;
+                        ci[rr * kKnnCap + pos] = col;
+                    }
+                    if (lane == 0) cnt[rr] = base + __popc(mh);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (compacted) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sg[i] = sig[wrow + (i & 3) + 8 * (i >> 2) + 4 * h];
+            }
+        }
     }
-    // rows are now sorted ascending (extraction order); write out, padding short rows
-    for (int e = tid; e < 64 * kKnnK; e += 256) {
-        const int r = e / kKnnK, s = e % kKnnK;
-        const uint32_t qr = row0 + r;
-        if (qr >= a.n || qr >= a.row_end) continue;
-        const bool have = (uint32_t)s < cnt[r];
-        a.out_ids[(size_t)qr * kKnnK + s] = have ? cand_i[r][s] : 0xFFFFFFFFu;
-        a.out_dist[(size_t)qr * kKnnK + s] = have ? cand_d[r][s] : 3.402823466e+38f;
+    // ---- results: every row sorted ascending by distance ----------------------------------------
+    for (int r = 0; r < 32; ++r) {
+        const uint32_t qr = row0 + wrow + r;
+        if (qr >= a.nq || qr >= a.row_end) break;
+        knn_compact(cs, ci, cnt, sig, wrow + r, lane);
+        if (lane < kKnnK) {
+            const bool have = (uint32_t)lane < cnt[wrow + r];
+            float d = 3.402823466e+38f;
+            if (have) {
+                d = a.qnorm[qr] - 2.0f * cs[(wrow + r) * kKnnCap + lane];
+                d = d > 0.0f ? d : 0.0f;
+            }
+            a.out_ids[(size_t)qr * kKnnK + lane] = have ? ci[(wrow + r) * kKnnCap + lane] : 0xFFFFFFFFu;
+            a.out_dist[(size_t)qr * kKnnK + lane] = d;
+        }
     }
 }
 
