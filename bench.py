@@ -1,26 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X-native CP-HNSW hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5|recall]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): SIFT1M-class synthetic data, 1M x 128 (D=128), 4-bit RaBitQ
-codes, R=32, index built in-bench by this repo's builder (GPU exact 32-NN + host pruning/encoding).
-k = the smallest of {10,20,50,100} whose dedup recall@10 reaches 0.95 (the reference returns
-duplicate slots).  A step = one `search_batch` pass of the layer-0 hot path over the
-rank's shard of a fixed query batch, queries resident in HBM, plus the RCCL all-gather of the
-results.  Queries shard across ranks; the index is replicated (weak scaling: nq per GPU fixed).
+Default workload = BASELINE.json configs[1] (c2): SIFT1M-class synthetic data, 1M x 128 (D=128),
+4-bit RaBitQ codes, R=32, index built in-bench by this repo's GPU builder, k=10 (the reference's
+default).  A step = one `search_batch_device` pass of the layer-0 hot path (query encoder, upper
+layer descent, beam search with FastScan estimates and exact-L2 rerank) over the rank's shard of a
+fixed query batch that is resident in HBM; results stay in HBM.  Steps are enqueued alternately on
+two HIP streams (the library keeps two sets of batch scratch), so a step starts while the previous
+one drains its longest queries; the K timed steps are bracketed by barrier + synchronize on both
+sides.  For N>1 the step also contains the RCCL all-gather of the shard results (the reference
+returns the whole batch: src/bindings.cpp:199-211).  Queries shard across ranks, the index is
+replicated (weak scaling: nq per GPU fixed).
+
+Other configs (parity-backed lines for profiles/, not the driver's default):
+  c3     GIST1M-class 1M x 960 (D=1024), 4-bit, two-stage MSB pipeline, generic-D search kernel
+  c4     Deep10M-class 10M x 96 (D=128), 4-bit
+  c5     streaming FastScan over the largest D=1024 / 2-bit block set that fits this GPU
+  recall Gaussian 100k x 128, 2-bit, k=20: a workload where the reference algorithm meets recall@10 >= 0.95
 
 The JSON line also carries
-  * fastscan_stream: the streaming FastScan kernel on 1M synthetic D=128/4-bit neighbour blocks
-    (metric part 2: distances/s vs the HBM roofline),
-  * roofline: the dominant kernel of the timed region (the persistent search kernel),
-    algorithmic bytes = expansions x (32 x 84 B) + exact-L2 evaluations x 516 B, measured with HIP
-    events on the launch stream inside the library,
-  * cpu_baseline: the reference (oracle/_ref) or the scalar port (oracle/) on this box' host
-    cores, on a bounded sample of the same workload.
+  * fastscan_stream: the streaming FastScan kernel on synthetic neighbour blocks of the config's
+    shape (metric part 2: distances/s vs the HBM roofline),
+  * roofline: the dominant kernel of the timed region (the persistent search kernel): algorithmic
+    bytes = expansions x 32 x (D*bits/8+20) B + exact-L2 evaluations x (4*D+4) B over its device time
+    (HIP events on the launch stream inside the library, steps serialised for this measurement),
+    `traffic` from the PMC summary file of the same tree when one is committed, else null,
+  * cpu_baseline: the compiled reference (oracle/_ref) or the scalar port (oracle/) on this box' host
+    cores, on a bounded sample of the same workload, with a bit-level parity check of its results
+    against the GPU's.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,66 +45,98 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
-DIM, BITS, K = 128, 4, 10
-BYTES_PER_DIST = DIM * BITS // 8 + 20      # 84 B
-BYTES_PER_EXACT = 4 * DIM + 4              # 516 B
+BUILDER_VERSION = "r2"         # part of the index cache key: bump when the builder changes
+
+CONFIGS = {
+    # name: generator, n, dim, bits, k, nq per GPU, stream blocks
+    "c2": dict(gen="sift", n=1_000_000, dim=128, bits=4, k=10, nq=10_000, stream_blocks=1_000_000, seed=1,
+               label="SIFT1M-class synthetic (int-valued, clustered; SURVEY 8d C2)"),
+    "c3": dict(gen="gist", n=1_000_000, dim=960, bits=4, k=10, nq=1_000, stream_blocks=200_000, seed=2,
+               label="GIST1M-class synthetic (500 clusters, sigma 0.05; SURVEY 8d C3)"),
+    "c4": dict(gen="deep", n=10_000_000, dim=96, bits=4, k=10, nq=10_000, stream_blocks=1_000_000, seed=3,
+               label="Deep10M-class synthetic (unit-norm, 2000 clusters; SURVEY 8d C4)"),
+    "recall": dict(gen="gauss", n=100_000, dim=128, bits=2, k=20, nq=10_000, stream_blocks=1_000_000, seed=5,
+                   label="Gaussian N(0,1) (BASELINE.md 2.2: the reference reaches recall@10 ~0.95 here)"),
+}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def sift_like(rng, n, dim, ncl, centers=None):
-    """SURVEY.md §8(d) C2 generator: clustered, integer-valued, clipped to [0, 218]."""
-    if centers is None:
-        centers = rng.gamma(2.0, 15.0, (ncl, dim))
-    X = centers[rng.integers(0, len(centers), n)] + rng.normal(0.0, 12.0, (n, dim))
-    return np.clip(np.round(X), 0, 218).astype(np.float32), centers
+def gen_rows(cfg, rng, n, centers):
+    g, dim = cfg["gen"], cfg["dim"]
+    if g == "sift":      # clustered, integer-valued, clipped to [0, 218]
+        X = centers[rng.integers(0, len(centers), n)] + rng.normal(0.0, 12.0, (n, dim))
+        return np.clip(np.round(X), 0, 218).astype(np.float32)
+    if g == "gist":      # U[0,1) cluster centres, sigma 0.05
+        out = np.empty((n, dim), np.float32)
+        for lo in range(0, n, 100_000):
+            hi = min(n, lo + 100_000)
+            out[lo:hi] = centers[rng.integers(0, len(centers), hi - lo)] + rng.normal(0.0, 0.05, (hi - lo, dim))
+        return out
+    if g == "deep":      # N(0,1) mixed with cluster centres, unit-normalised
+        out = np.empty((n, dim), np.float32)
+        for lo in range(0, n, 500_000):
+            hi = min(n, lo + 500_000)
+            v = centers[rng.integers(0, len(centers), hi - lo)] + 0.6 * rng.normal(0.0, 1.0, (hi - lo, dim))
+            out[lo:hi] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        return out
+    return rng.normal(0.0, 1.0, (n, dim)).astype(np.float32)
 
 
-def make_data(n, nq, seed=1, need_base=True):
-    """Queries are drawn first so that ranks that never touch the base vectors can skip them."""
-    rng = np.random.default_rng(seed)
-    ncl = max(10, n // 1000)
-    centers = rng.gamma(2.0, 15.0, (ncl, DIM))
-    Q, _ = sift_like(rng, nq, DIM, ncl, centers)
-    X = None
-    if need_base:
-        X, _ = sift_like(rng, n, DIM, ncl, centers)
-    return X, Q
+def make_centers(cfg, n):
+    rng = np.random.default_rng([cfg["seed"], 0])
+    g, dim = cfg["gen"], cfg["dim"]
+    if g == "sift":
+        return rng.gamma(2.0, 15.0, (max(10, n // 1000), dim))
+    if g == "gist":
+        return rng.random((500, dim))
+    if g == "deep":
+        return rng.normal(0.0, 1.0, (2000, dim))
+    return None
 
 
-def get_index_file(args, rank, X, local):
-    """Builds the C2 index with our own builder (GPU exact 32-NN + host pruning/encoding/calibration,
-    csrc/builder*.h) on rank 0 and hands it to every rank as a v2 file."""
-    path = os.path.join(args.workdir, f"bench_n{args.n_index}_b{BITS}.idx")
+def make_base(cfg, n):
+    """Base vectors: their own seeded stream, independent of the world size and of the query count."""
+    return gen_rows(cfg, np.random.default_rng([cfg["seed"], 1]), n, make_centers(cfg, n))
+
+
+def make_queries(cfg, n, nq):
+    return gen_rows(cfg, np.random.default_rng([cfg["seed"], 2]), nq, make_centers(cfg, n))
+
+
+def index_path(args, cfg, n):
+    key = hashlib.sha1(json.dumps([cfg["gen"], cfg["seed"], n, cfg["dim"], cfg["bits"], BUILDER_VERSION]).encode()).hexdigest()[:12]
+    return os.path.join(args.workdir, f"bench_{args.config}_{key}.idx")
+
+
+def get_index_file(args, cfg, n, rank, local):
+    """Builds the index with this repo's builder on rank 0 and hands it to every rank as a v2 file."""
+    path = index_path(args, cfg, n)
     info = {"builder": "cphnsw_mi355x (this repo)", "build_s": None}
-    if rank == 0 and not os.path.exists(path):
-        import cphnsw_mi355x
-        t0 = time.time()
-        idx = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
-        idx.build(X)
-        idx.finalize()
-        idx.save(path + ".tmp")
-        os.replace(path + ".tmp", path)
-        del idx
-        info["build_s"] = round(time.time() - t0, 1)
-        log(f"[bench] built n={args.n_index} in {info['build_s']} s")
-    return path, info
+    X = None
+    if rank == 0:
+        X = make_base(cfg, n)
+        if not os.path.exists(path):
+            import cphnsw_mi355x
+            t0 = time.time()
+            idx = cphnsw_mi355x.CPIndex(cfg["dim"], cfg["bits"], device=local)
+            idx.build(X)
+            idx.finalize()
+            info["build_s"] = round(time.time() - t0, 1)
+            idx.save(path + ".tmp")
+            os.replace(path + ".tmp", path)
+            del idx
+            log(f"[bench] built n={n} dim={cfg['dim']} bits={cfg['bits']} in {info['build_s']} s")
+    return path, info, X
 
 
-def ground_truth(X, Q, k, dev):
-    """Exact k-th nearest squared distances by brute force (torch fp32 GEMM on the GPU; plumbing for
-    the recall protocol only)."""
-    import torch
-    xb = torch.from_numpy(X).to(dev)
-    xn = (xb * xb).sum(1)
-    out = []
-    for lo in range(0, len(Q), 2048):
-        q = torch.from_numpy(Q[lo:lo + 2048]).to(dev)
-        d = (q * q).sum(1)[:, None] + xn[None, :] - 2.0 * (q @ xb.T)
-        out.append(torch.topk(d, k, dim=1, largest=False).values.clamp_min(0).cpu())
-    return torch.cat(out).numpy()
+def ground_truth(X, Q, local):
+    """Exact nearest squared distances (ascending, 32 per query) on the matrix cores (csrc/device_knn.h)."""
+    import cphnsw_mi355x
+    _, d = cphnsw_mi355x.knn_bruteforce(X, queries=Q, device=local)
+    return d
 
 
 def recall_at_10(ids, dist, gt_d, dedup):
@@ -118,47 +163,52 @@ def recall_at_10(ids, dist, gt_d, dedup):
     return hits / (10.0 * len(ids))
 
 
-def cpu_baseline(args, path, Q, stream, K, gpu_index=None):
+def cpu_baseline(args, cfg, path, Q, stream, K, gpu_index=None):
     """Reference (or port) on the host cores: bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, RefHooks, ref_available, ref_module
     cores = os.cpu_count() or 1
     out = {"cores": cores}
+    dim, bits = cfg["dim"], cfg["bits"]
+    D = 1 << (dim - 1).bit_length()
     sample_q = Q[: min(len(Q), args.cpu_queries)]
     if ref_available():
-        idx = ref_module().CPIndex(DIM, BITS)
+        idx = ref_module().CPIndex(dim, bits)
         idx.load(path)
         idx.search_batch(sample_q[:64], K)
         t0 = time.time()
-        idx.search_batch(sample_q, K)
+        r_ids, r_d = idx.search_batch(sample_q, K)
         dt = time.time() - t0
         out.update(kind="reference", value=len(sample_q) / dt, unit="queries/s")
         if gpu_index is not None:
             # full-size parity: the reference's CPU results on this index vs the GPU's, bit for bit
-            r_ids, r_d = idx.search_batch(sample_q, K)
             g_ids, g_d = gpu_index.search_batch(sample_q, K)
             out["parity_vs_reference"] = {
                 "queries": int(len(sample_q)), "k": int(K),
                 "ids_identical": bool(np.array_equal(r_ids, g_ids)),
                 "distances_bit_identical": bool(r_d.tobytes() == g_d.tobytes())}
+        del idx
         # streaming FastScan, same blocks and query as the GPU stream leg
-        L = Oracle().layout(DIM, BITS)
-        nb = min(stream.n_blocks, 200_000)
-        blocks, lut, qp, dqp = stream.export(0, nb, L[0] - L[1])
-        import ctypes as C
-        r = RefHooks()
-        f = r.lib.ref_fastscan_stream
-        ck = C.c_double()
-        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_int,
-                      C.POINTER(C.c_double)]
-        f(DIM, BITS, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, 1, C.byref(ck))
-        reps = 8
-        t0 = time.time()
-        f(DIM, BITS, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, reps, C.byref(ck))
-        dt2 = time.time() - t0
-        out["fastscan_dist_per_s"] = nb * 32 * reps / dt2
-        out["sample"] = (f"{len(sample_q)} queries of the same batch on the same index, k={K}, "
-                         f"search_batch with {cores} OpenMP threads; FastScan: {nb} of the same blocks x {reps}")
+        if stream is not None:
+            L = Oracle().layout(D, bits)
+            nb = min(stream.n_blocks, 200_000 if D <= 128 else 25_000)
+            blocks, lut, qp, dqp = stream.export(0, nb, L[0] - L[1])
+            import ctypes as C
+            r = RefHooks()
+            f = r.lib.ref_fastscan_stream
+            ck = C.c_double()
+            f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_float, C.c_int,
+                          C.POINTER(C.c_double)]
+            f(D, bits, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, 1, C.byref(ck))
+            reps = 8
+            t0 = time.time()
+            f(D, bits, lut.ctypes.data, qp.ctypes.data, blocks.ctypes.data, nb, dqp, reps, C.byref(ck))
+            dt2 = time.time() - t0
+            out["fastscan_dist_per_s"] = nb * 32 * reps / dt2
+            out["sample"] = (f"{len(sample_q)} queries of the same batch on the same index, k={K}, "
+                             f"search_batch with {cores} OpenMP threads; FastScan: {nb} of the same blocks x {reps}")
+        else:
+            out["sample"] = f"{len(sample_q)} queries of the same batch on the same index, k={K}, {cores} OpenMP threads"
     else:
         oi = Oracle().load(path)
         sample_q = sample_q[: max(64, args.cpu_queries // 8)]
@@ -170,18 +220,102 @@ def cpu_baseline(args, path, Q, stream, K, gpu_index=None):
     return out
 
 
+def pmc_traffic_ratio(config, k):
+    """HBM bytes over algorithmic bytes of the search kernel, from the PMC summary committed for this
+    tree (profiles/r2_pmc_search.json, written by scripts/pmc_search.sh + scripts/pmc_summary.py from
+    separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 FETCH_SIZE correction).  None when the
+    file does not cover this workload."""
+    p = os.path.join(ROOT, "profiles", "r2_pmc_search.json")
+    try:
+        rec = json.load(open(p))
+    except Exception:
+        return None
+    if rec.get("config") != config or rec.get("k") != k:
+        return None
+    return rec.get("hbm_bytes_over_algorithmic")
+
+
+def bench_stream_c5(args, local, world, rank, use_dist, dist, dev):
+    """C5: streaming FastScan over the largest D=1024 / 2-bit block set that fits this GPU.
+    Blocks only (random valid codes / aux), one encoded query, both N-bit stages per block."""
+    import torch
+    import cphnsw_mi355x
+    D, bits = 1024, 2
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    stride = 32 * bits * (D // 32) * 4 + 512 + 128 + 64
+    n_blocks = args.stream_blocks if args.stream_blocks else int(min(25_000_000, free_b * 0.92 // stride))
+    stream = cphnsw_mi355x.FastScanStream(D, bits, n_blocks, seed=4 + rank, device=local)
+    bpd = D * bits // 8 + 20
+    stream.run(max(1, args.warmup))
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms, _ = stream.run(args.steps)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    dps = world * n_blocks * 32 * args.steps / elapsed
+    gbs = n_blocks * 32 * bpd / (ms * 1e-3) / 1e9
+    # parity of this instantiation on a sample of its own blocks against the oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    orc = Oracle()
+    L = orc.layout(D, bits)
+    nbb = L[0] - L[1]
+    first = max(0, n_blocks - 64)
+    blocks, lut, qp, dqp = stream.export(first, 64, nbb)
+    est, lower = stream.eval(first, 64)
+    ok = True
+    for b in range(64):
+        nb = blocks.reshape(64, nbb)[b]
+        planes = nb[L[2]:L[2] + bits * D * 4].reshape(bits, D // 8, 32)
+        s, m = orc.fastscan_nbit(D, bits, lut, planes)
+        e, lo = orc.convert_nbit(D, bits, qp, s, m, nb[L[3]:L[3] + 128].view(np.float32),
+                                 nb[L[4]:L[4] + 128].view(np.float32), nb[L[5]:L[5] + 128].view(np.float32),
+                                 nb[L[6]:L[6] + 64].view(np.uint16), nb[L[7]:L[7] + 64].view(np.uint16), dqp)
+        ok = ok and est[b].tobytes() == e.tobytes() and lower[b].tobytes() == lo.tobytes()
+    out = {
+        "metric": "fastscan_dist_per_s (streaming FastScan, both N-bit stages, vs HBM roofline)",
+        "value": dps, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32 popcount / f32", "data": "synthetic",
+        "config": {"workload": f"C5 stress: D=1024 (768-dim class), 2-bit codes, {n_blocks} neighbour blocks "
+                               f"({n_blocks * stride / 1e9:.1f} GB) per GPU, blocks only, random valid codes/aux; the vectors "
+                               "themselves (bf16 in BASELINE's wording) are never read by this path: FastScan consumes "
+                               "only the 2-bit codes and the fp32 aux values",
+                   "D": D, "bits": bits, "blocks_per_gpu": n_blocks, "block_bytes": stride,
+                   "parallelism": f"block-sharded x{world}, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "fastscan_stream_kernel<2,0>", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "kernel_ms": ms,
+                     "traffic": n_blocks * stride / (ms * 1e-3) / 1e9,
+                     "traffic_note": "the kernel reads every block once: n_blocks x stride (PMC-calibrated, profiles/r1_pmc_summary.md)"},
+        "parity_vs_oracle": {"blocks": 64, "est_and_lower_bit_identical": bool(ok)},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 1_000_000)))
-    ap.add_argument("--nq-per-gpu", type=int, default=10_000)
-    ap.add_argument("--stream-blocks", type=int, default=1_000_000)
+    ap.add_argument("--config", default="c2", choices=sorted(list(CONFIGS) + ["c5"]))
+    ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 0)), help="override the config's n")
+    ap.add_argument("--nq-per-gpu", type=int, default=0)
+    ap.add_argument("--stream-blocks", type=int, default=0)
     ap.add_argument("--cpu-queries", type=int, default=2_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--k", type=int, default=0, help="0 = smallest k in {10,20,50,100} with dedup recall@10 >= 0.95")
+    ap.add_argument("--k", type=int, default=0, help="0 = the config's k")
     ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--serial", action="store_true", help="one stream: every step waits for the previous one")
     ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
     args = ap.parse_args()
 
@@ -203,112 +337,129 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     os.makedirs(args.workdir, exist_ok=True)
 
+    if args.config == "c5":
+        bench_stream_c5(args, local, world, rank, use_dist, dist, dev)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     import cphnsw_mi355x
     from cphnsw_mi355x.dist import gather_results
 
+    cfg = CONFIGS[args.config]
+    n = args.n_index or cfg["n"]
+    dim, bits = cfg["dim"], cfg["bits"]
+    D = 1 << (dim - 1).bit_length()
+    nq_gpu = args.nq_per_gpu or cfg["nq"]
+    k_run = args.k or cfg["k"]
+    bytes_per_dist = D * bits // 8 + (20 if bits > 1 else 18)
+    bytes_per_exact = 4 * D + 4
+
     # ---- data, index ----------------------------------------------------------------------
-    nq_total = args.nq_per_gpu * world
-    X, Q = make_data(args.n_index, nq_total, need_base=(rank == 0))
-    path, build_info = get_index_file(args, rank, X, local)
+    nq_total = nq_gpu * world
+    Q = make_queries(cfg, n, nq_total)
+    path, build_info, X = get_index_file(args, cfg, n, rank, local)
     if use_dist:
         dist.barrier()
-    index = cphnsw_mi355x.CPIndex(DIM, BITS, device=local)
+    index = cphnsw_mi355x.CPIndex(dim, bits, device=local)
     t0 = time.time()
     index.load(path)
     load_s = time.time() - t0
-    q_shard = torch.from_numpy(Q[rank * args.nq_per_gpu:(rank + 1) * args.nq_per_gpu]).to(dev)
+    q_shard = torch.from_numpy(Q[rank * nq_gpu:(rank + 1) * nq_gpu]).to(dev)
 
-    # ---- recall protocol (rank 0, outside the timed region) -> the k the metric is quoted at ----
+    # ---- recall protocol (rank 0, outside the timed region) --------------------------------
     recall = {}
-    k_run = args.k if args.k > 0 else 10
     if rank == 0 and X is not None:
         nrq = min(args.recall_queries, len(Q))
-        gt_d = ground_truth(X, Q[:nrq], 10, dev)
-        for kk in (10, 20, 50, 100):
+        gt_d = ground_truth(X, Q[:nrq], local)
+        for kk in sorted({10, 20, 100, k_run}):
             ids_r, d_r = index.search_batch(Q[:nrq], kk)
             recall[f"k{kk}_dedup"] = recall_at_10(ids_r, d_r, gt_d, True)
             if kk == 10:
                 recall["k10_raw"] = recall_at_10(ids_r, d_r, gt_d, False)
-        if args.k == 0:
-            ok = [kk for kk in (10, 20, 50, 100) if recall[f"k{kk}_dedup"] >= 0.95]
-            k_run = ok[0] if ok else 10   # target unreachable for the reference algorithm here: its default k
-        log(f"[bench] recall@10: {recall} -> k={k_run}")
-    if use_dist:
-        kt = torch.tensor([k_run], device=dev)
-        dist.broadcast(kt, 0)
-        k_run = int(kt.item())
+        log(f"[bench] recall@10: {recall} (k={k_run})")
     del X
 
-    def step():
-        # the path shards by query with no exchange step: every rank answers its own shard, results
-        # stay in its HBM (the optional all-gather of search_batch_sharded is exercised once, untimed,
-        # after the timed region)
-        return index.search_batch_device(q_shard, k_run)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [(torch.empty((nq_gpu, k_run), dtype=torch.int64, device=dev),
+             torch.empty((nq_gpu, k_run), dtype=torch.float32, device=dev)) for _ in range(2)]
 
-    # ---- end-to-end search ----------------------------------------------------------------
-    log(f"[bench] rank {rank}: timed region, k={k_run}")
-    for _ in range(args.warmup):
-        step()
-    kernel_us = []
-    stats = None
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids, d = step()
-        stats = index.last_search_stats()
-        kernel_us.append(stats["kernel_us"])
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    qps = nq_total * args.steps / elapsed
-    log(f"[bench] rank {rank}: {qps:.0f} q/s")
-    if use_dist:   # RCCL plumbing check, outside the timed region
-        g_ids, g_d = gather_results(ids, d, world, force=True)
-        assert g_ids.shape[0] == nq_total and g_d.shape[0] == nq_total
+    def step(i, serial):
+        # The path shards by query with no exchange step inside the search; with N > 1 the step ends
+        # with the result all-gather (reference semantics: the whole batch comes back).
+        st = streams[0 if serial else (i & 1)]
+        ids, d = index.search_batch_device(q_shard, k_run, out=outs[0 if serial else (i & 1)], stream=st)
+        if use_dist:
+            with torch.cuda.stream(st):
+                gather_results(ids, d, world, force=True)
+        return ids, d
 
-    # roofline of the dominant kernel (persistent search kernel), rank 0's launches
-    k_s = float(np.mean(kernel_us)) * 1e-6
-    alg_bytes = stats["expansions"] * 32 * BYTES_PER_DIST + stats["exact_l2"] * BYTES_PER_EXACT
-    # HBM traffic of the search kernel from the PMC passes of this round (profiles/r1_pmc_sq_summary.md:
-    # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs on this workload): 1.11 x the algorithmic
-    # bytes; expressed like `achieved`.  Only claimed for the workload it was measured on.
-    pmc_valid = (args.n_index == 1_000_000 and k_run == 10)
-    search_traffic = (1.11 * alg_bytes / k_s / 1e9) if (pmc_valid and k_s > 0) else None
-    achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
-
-    # k=10 (the reference's default k) for comparison when the metric k differs
-    qps_k10 = None
-    if k_run != 10:
-        for _ in range(2):
-            index.search_batch_device(q_shard, 10)
+    def timed(steps, serial):
+        for i in range(args.warmup):
+            step(i, serial)
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            index.search_batch_device(q_shard, 10)
+        for i in range(steps):
+            ids, d = step(i, serial)
         torch.cuda.synchronize()
-        qps_k10 = args.nq_per_gpu * args.steps / (time.perf_counter() - t0)
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ids, d
+
+    # ---- the timed region ------------------------------------------------------------------------
+    log(f"[bench] rank {rank}: timed region, k={k_run}")
+    elapsed, ids, d = timed(args.steps, args.serial)
+    qps = nq_total * args.steps / elapsed
+    log(f"[bench] rank {rank}: {qps:.0f} q/s")
+
+    # ---- the search kernel alone (steps serialised on one stream, HIP events inside the library) ----
+    kernel_us = []
+    stats = None
+    for i in range(args.warmup + args.steps):
+        index.search_batch_device(q_shard, k_run, out=outs[0], stream=streams[0])
+        if i >= args.warmup:
+            stats = index.last_search_stats()
+            kernel_us.append(stats["kernel_us"])
+    k_s = float(np.mean(kernel_us)) * 1e-6
+    alg_bytes = stats["expansions"] * 32 * bytes_per_dist + stats["exact_l2"] * bytes_per_exact
+    achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
+    ratio = pmc_traffic_ratio(args.config, k_run)
+    search_traffic = ratio * achieved if ratio else None
+    el_serial, _, _ = timed(args.steps, True)
+    qps_serial = nq_total * args.steps / el_serial
+
+    # the drop-in entry point: host numpy in, numpy out (PCIe inclusive; never `value`)
+    q_host = Q[rank * nq_gpu:(rank + 1) * nq_gpu]
+    index.search_batch(q_host, k_run)
+    t0 = time.perf_counter()
+    reps = max(3, args.steps // 4)
+    for _ in range(reps):
+        index.search_batch(q_host, k_run)
+    qps_host = nq_gpu * reps / (time.perf_counter() - t0)
 
     # ---- FastScan stream (metric part 2) -----------------------------------------------------
-    stream = cphnsw_mi355x.FastScanStream(DIM, BITS, args.stream_blocks, seed=4, device=local)
-    stream.run(300)          # ~150 ms of back-to-back passes: the chip reaches its steady clock
-    ms, _ = stream.run(100)
-    fs_dist_s = args.stream_blocks * 32 / (ms * 1e-3)
-    fs_gbs = fs_dist_s * BYTES_PER_DIST / 1e9
-    # PMC-calibrated: the stream kernel fetches exactly n_blocks x stride bytes per pass
-    # (profiles/r1_pmc_summary.md); expressed like `achieved`
-    fs_traffic = args.stream_blocks * stream.block_bytes / (ms * 1e-3) / 1e9
+    sb = args.stream_blocks or cfg["stream_blocks"]
+    stream = cphnsw_mi355x.FastScanStream(D, bits, sb, seed=4, device=local)
+    stream.run(300 if D <= 128 else 40)          # back-to-back passes: the chip reaches its steady clock
+    ms, _ = stream.run(100 if D <= 128 else 20)
+    fs_dist_s = sb * 32 / (ms * 1e-3)
+    fs_gbs = fs_dist_s * bytes_per_dist / 1e9
+    fs_traffic = sb * stream.block_bytes / (ms * 1e-3) / 1e9
 
     if rank == 0:
         ids_np = ids.cpu().numpy()
+        kname = f"search_kernel<{bits},{D if D == 128 else 0}>"
+        gate = bool(recall and recall.get(f"k{k_run}_dedup", 0.0) >= 0.95)
         out = {
-            "metric": "qps (search_batch at the smallest k with dedup recall@10>=0.95, else k=10) + fastscan_dist_per_s",
+            "metric": "qps (search_batch_device, layer-0 hot path end to end) + fastscan_dist_per_s",
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
@@ -320,34 +471,43 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 popcount / f32",
             "data": "synthetic",
-            "config": {"workload": f"SIFT1M-class synthetic {args.n_index}x{DIM} f32 (int-valued, clustered; "
-                                   f"SURVEY 8d C2), {BITS}-bit RaBitQ FastScan + exact-L2 rerank, R=32, "
-                                   f"k={k_run}, {args.nq_per_gpu} queries per GPU resident in HBM",
-                       "n_index": args.n_index, "dim": DIM, "bits": BITS, "k": k_run,
-                       "nq_per_gpu": args.nq_per_gpu, "index_builder": build_info["builder"],
+            "config": {"workload": f"{cfg['label']}: {n}x{dim} f32 (D={D}), {bits}-bit RaBitQ FastScan + exact-L2 "
+                                   f"rerank, R=32, k={k_run}, {nq_gpu} queries per GPU resident in HBM",
+                       "name": args.config, "n_index": n, "dim": dim, "bits": bits, "k": k_run,
+                       "nq_per_gpu": nq_gpu, "index_builder": build_info["builder"],
                        "index_build_s": build_info["build_s"],
+                       "step": ("one stream, each step waits for the previous one" if args.serial else
+                                "steps alternate between two HIP streams (two batch scratch sets): a step starts "
+                                "while the previous one drains") + ("; ends with the RCCL all-gather" if use_dist else ""),
                        "parallelism": f"query-sharded x{world}, index replicated"},
             "recall_at_10": recall,
-            "recall_target_met": bool(recall and recall.get(f"k{k_run}_dedup", 0.0) >= 0.95),
-            "qps_k10": qps_k10 if qps_k10 is not None else qps,
-            "fastscan_stream": {"dist_per_s": fs_dist_s, "blocks": args.stream_blocks,
-                                "ms_per_pass": ms, "bytes_per_dist": BYTES_PER_DIST,
+            "recall_target_met": gate,
+            "recall_note": ("recall@10 >= 0.95 holds at this k" if gate else
+                            "the reference algorithm itself does not reach recall@10 >= 0.95 on this data at any k <= 100 "
+                            "(ids are bit-identical to the reference's); see the `recall` config for a gate-meeting workload"),
+            "qps_serial": qps_serial,
+            "qps_host_api": qps_host,
+            "fastscan_stream": {"dist_per_s": fs_dist_s, "blocks": sb, "ms_per_pass": ms,
+                                "bytes_per_dist": bytes_per_dist,
                                 "roofline": {"bound": "hbm", "achieved": fs_gbs, "peak": HBM_PEAK_GBS,
                                              "unit": "GB/s", "frac": fs_gbs / HBM_PEAK_GBS,
                                              "traffic": fs_traffic}},
-            "roofline": {"bound": "hbm", "kernel": "search_kernel<4,128>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": search_traffic, "kernel_ms": k_s * 1e3,
+                         "measured": "kernel alone: steps serialised on one stream, HIP events around the search launches",
+                         "pipelined_achieved": alg_bytes * args.steps / elapsed / 1e9,
+                         "pipelined_frac": alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "peak_note": "achievable with this access shape (bare gather/read kernels, "
                                       "profiles/r1_hbm_read_microbench.txt): 6.3-6.4 TB/s",
-                         "expansions_per_query": stats["expansions"] / args.nq_per_gpu,
-                         "exact_l2_per_query": stats["exact_l2"] / args.nq_per_gpu},
+                         "expansions_per_query": stats["expansions"] / nq_gpu,
+                         "exact_l2_per_query": stats["exact_l2"] / nq_gpu},
             "search_stats": stats,
             "index_load_s": load_s,
             "dup_slots_per_query": float((ids_np[:, 1:] == ids_np[:, :-1]).sum(1).mean()),
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, path, Q, stream, k_run, index)
+            out["cpu_baseline"] = cpu_baseline(args, cfg, path, Q, stream, k_run, index)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -692,6 +692,123 @@ int orc_convert_nbit(int, int bits, const float* qp, const uint32_t* nbit, const
 int orc_dot(int D, const float* a, const float* b, float* out) { *out = dot8(D, a, b); return 0; }
 int orc_l2(int D, const float* a, const float* b, float* out) { *out = l2sq8(D, a, b); return 0; }
 
+// ---------------------------------------------------------------------------------
+// Data-side encoder of one vertex' edges: encoder/rabitq_encoder.hpp:138-181 (1 bit),
+// :287-323 + caq_quantize :371-467 (N bits).  Scalar reference code compiled with GCC's
+// default -ffp-contract=fast: every a*b+c below is the fused form the compiler emits
+// (pinned bit-for-bit against ref_encode_edges by tests/test_oracle_golden.py).
+// values u8[cnt][D], aux f32[cnt][3] = {nop, ip_qo, ip_cp}, pops u32[cnt][2] = {msb, weighted}.
+// ---------------------------------------------------------------------------------
+int orc_encode_edges(int dim, int D, int bits, const float* parent, const float* nbrs, int cnt,
+                     uint8_t* values, float* aux, uint32_t* pops) {
+    Rotation rot(D);
+    const float d = static_cast<float>(D);
+    const float norm_factor = 1.0f / (d * std::sqrt(d));
+    const float inv_sqrt_d = 1.0f / std::sqrt(d);
+    std::vector<float> rp(D, 0.0f), diff(D), x(D);
+    std::memcpy(rp.data(), parent, dim * sizeof(float));
+    rot.apply(rp.data());
+    for (int i = 0; i < D; ++i) rp[i] *= norm_factor;
+    const int Ki = (1 << bits) - 1;
+    const float K = static_cast<float>(Ki);
+    std::vector<int> u(D);
+    for (int e = 0; e < cnt; ++e) {
+        const float* nb = nbrs + (size_t)e * dim;
+        uint8_t* val = values + (size_t)e * D;
+        std::memset(val, 0, D);
+        aux[3 * e] = aux[3 * e + 1] = aux[3 * e + 2] = 0.0f;
+        pops[2 * e] = pops[2 * e + 1] = 0;
+        float nsq = 0.0f;
+        for (int i = 0; i < dim; ++i) { diff[i] = nb[i] - parent[i]; 
+            // GCC vectorises this in-order reduction (8-wide, then a 4-wide epilogue: products rounded, added
+            // in order); only the scalar remainder of dim % 4 elements gets the fused form
+            if (i < dim - dim % 4) nsq += diff[i] * diff[i]; else nsq = std::fmaf(diff[i], diff[i], nsq);
+        }
+        for (int i = dim; i < D; ++i) diff[i] = 0.0f;
+        const float nop = std::sqrt(nsq);
+        aux[3 * e] = nop;
+        if (nop < 1e-8f / d) continue;
+        const float inv = 1.0f / nop;
+        for (int i = 0; i < D; ++i) x[i] = diff[i] * inv;
+        rot.apply(x.data());
+        for (int i = 0; i < D; ++i) x[i] *= norm_factor;
+        if (bits == 1) {
+            float l1 = 0.0f, ipcp = 0.0f;
+            uint32_t pc = 0;
+            for (int i = 0; i < D; ++i) { val[i] = x[i] >= 0.0f ? 1 : 0; l1 += std::fabs(x[i]); pc += val[i]; }
+            for (int i = 0; i < D; ++i) ipcp += (val[i] ? 1.0f : -1.0f) * rp[i];
+            aux[3 * e + 1] = l1 * inv_sqrt_d;
+            aux[3 * e + 2] = ipcp * inv_sqrt_d;
+            pops[2 * e] = pops[2 * e + 1] = pc;
+            continue;
+        }
+        float mn = x[0], mx = x[0];
+        for (int i = 1; i < D; ++i) { if (x[i] < mn) mn = x[i]; if (x[i] > mx) mx = x[i]; }
+        float delta = (mx - mn) / K;
+        if (delta < 1e-10f / d) delta = 1e-10f / d;
+        const float inv_delta = 1.0f / delta;
+        float dot = 0.0f, nrm = 0.0f;
+        for (int i = 0; i < D; ++i) {
+            int q = static_cast<int>(std::fmaf(x[i] - mn, inv_delta, 0.5f));
+            q = q < 0 ? 0 : (q > Ki ? Ki : q);
+            u[i] = q;
+            const float c = (2.0f * q - K) / K;
+            dot += c * x[i];      // vectorised in-order reductions (the pass always runs whole vectors of
+            nrm += c * c;         // the padded dimension): products rounded before the add
+        }
+        float prev = 0.0f;
+        for (int iter = 0; iter < 10; ++iter) {
+            bool changed = false;
+            for (int i = 0; i < D; ++i) {
+                const int ou = u[i];
+                const float oc = (2.0f * ou - K) / K;
+                const float dwo = std::fmaf(-oc, x[i], dot);
+                const float nwo = std::fmaf(-oc, oc, nrm);
+                int bu = ou;
+                float bd = dot, bn = nrm;
+                auto consider = [&](int t) {
+                    const float c = (2.0f * t - K) / K;
+                    const float nd = std::fmaf(c, x[i], dwo);
+                    const float nn = std::fmaf(c, c, nwo);
+                    if (nd * nd * bn > bd * bd * nn) { bu = t; bd = nd; bn = nn; }
+                };
+                if (bits >= 4) {
+                    if (ou - 1 >= 0) consider(ou - 1);
+                    if (ou + 1 <= Ki) consider(ou + 1);
+                } else {
+                    for (int t = 0; t <= Ki; ++t) if (t != ou) consider(t);
+                }
+                if (bu != ou) {
+                    const float nc = (2.0f * bu - K) / K;
+                    dot = std::fmaf(nc, x[i], dwo);
+                    nrm = std::fmaf(nc, nc, nwo);
+                    u[i] = bu;
+                    changed = true;
+                }
+            }
+            if (!changed) break;
+            const float cs = nrm > 0.0f ? dot * dot / nrm : 0.0f;
+            if (iter > 0 && (cs - prev) < 1e-4f) break;
+            prev = cs;
+        }
+        float ipqo = 0.0f, ipcp = 0.0f;
+        uint32_t msb = 0, wp = 0;
+        for (int i = 0; i < D; ++i) {
+            val[i] = static_cast<uint8_t>(u[i]);
+            const float c = (2.0f * u[i] - K) / K;
+            ipqo = std::fmaf(c, x[i], ipqo);
+            ipcp = std::fmaf(c, rp[i], ipcp);
+            wp += (uint32_t)u[i];
+            msb += (uint32_t)((u[i] >> (bits - 1)) & 1);
+        }
+        aux[3 * e + 1] = ipqo * inv_sqrt_d;
+        aux[3 * e + 2] = ipcp * inv_sqrt_d;
+        pops[2 * e] = msb;
+        pops[2 * e + 1] = wp;
+    }
+    return 0;
+}
+
 static thread_local std::string g_err;
 const char* orc_last_error() { return g_err.c_str(); }
 

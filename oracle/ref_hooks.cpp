@@ -124,6 +124,57 @@ int ref_encode_query(int dim, int Dv, const float* q, uint8_t* lut, float* coeff
     return 0;
 }
 
+// Data-side encoder of one vertex' edges (encoder/rabitq_encoder.hpp:138-181 for 1 bit, :287-323 +
+// caq_quantize :371-467 for N bits): parent and cnt neighbours (dim floats each) ->
+// values u8[cnt][D] (code value per dimension, 0..2^bits-1), aux f32[cnt][3] = {nop, ip_qo, ip_cp},
+// pops u32[cnt][2] = {msb popcount, weighted popcount}.  Checker for the GPU edge encoder.
+int ref_encode_edges(int dim, int Dv, int bits, const float* parent, const float* nbrs, int cnt,
+                     uint8_t* values, float* aux, uint32_t* pops) {
+    if (bits == 1) {
+        DISPATCH_D(Dv, {
+            RaBitQEncoder<D> enc(static_cast<size_t>(dim));
+            alignas(64) float pp[D];
+            alignas(64) float rp[D];
+            std::memcpy(pp, parent, dim * sizeof(float));
+            for (size_t i = dim; i < D; ++i) pp[i] = 0.0f;
+            enc.rotate_raw_vector(pp, rp);
+            for (int e = 0; e < cnt; ++e) {
+                BinaryCodeStorage<D> code;
+                VertexAuxData a = enc.compute_neighbor_aux(parent, nbrs + (size_t)e * dim, rp, code);
+                uint32_t pc = 0;
+                for (size_t d = 0; d < D; ++d) {
+                    const uint8_t bit = (code.signs[d / 64] >> (d % 64)) & 1u;
+                    values[(size_t)e * D + d] = bit;
+                    pc += bit;
+                }
+                aux[3 * e] = a.nop; aux[3 * e + 1] = a.ip_qo; aux[3 * e + 2] = a.ip_cp;
+                pops[2 * e] = pc; pops[2 * e + 1] = pc;
+            }
+        })
+        return 0;
+    }
+    DISPATCH_BW(bits, DISPATCH_D(Dv, {
+        NbitRaBitQEncoder<D, BW> enc(static_cast<size_t>(dim));
+        alignas(64) float pp[D];
+        alignas(64) float rp[D];
+        std::memcpy(pp, parent, dim * sizeof(float));
+        for (size_t i = dim; i < D; ++i) pp[i] = 0.0f;
+        enc.rotate_raw_vector(pp, rp);
+        for (int e = 0; e < cnt; ++e) {
+            auto r = enc.compute_neighbor_aux_nbit(parent, nbrs + (size_t)e * dim, rp);
+            for (size_t d = 0; d < D; ++d) {
+                uint8_t v = 0;
+                for (size_t b = 0; b < BW; ++b)
+                    v = (uint8_t)((v << 1) | ((r.code.planes[b][d / 64] >> (d % 64)) & 1u));
+                values[(size_t)e * D + d] = v;
+            }
+            aux[3 * e] = r.aux.nop; aux[3 * e + 1] = r.aux.ip_qo; aux[3 * e + 2] = r.aux.ip_cp;
+            pops[2 * e] = r.code.msb_popcount(); pops[2 * e + 1] = r.code.weighted_popcount();
+        }
+    }))
+    return 0;
+}
+
 // One plane: block = u8[D/8][32]; out = u32[32].
 int ref_fastscan_plane(int Dv, const uint8_t* lut, const uint8_t* block, uint32_t* out) {
     DISPATCH_D(Dv, {

@@ -24,3 +24,11 @@ def oracle():
 def gold():
     from golden_util import golden
     return golden()
+
+
+@pytest.fixture(scope="session")
+def gold_build():
+    """Construction-side golden vectors (tests/golden/make_golden_build.py)."""
+    import numpy as np
+    from golden_util import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, "golden_build.npz"))

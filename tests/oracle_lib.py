@@ -116,6 +116,20 @@ class _Hooks:
                  _c(pop, np.uint16), _c(wpop, np.uint16), count, float(dqp), est, lo) == 0
         return est, lo
 
+    def encode_edges(self, parent, nbrs, D, bits):
+        """Data-side encoder of one vertex' edges -> (values u8[cnt,D], aux f32[cnt,3] = nop, ip_qo, ip_cp,
+        pops u32[cnt,2] = msb popcount, weighted popcount)."""
+        parent = _c(parent, np.float32)
+        nbrs = _c(nbrs, np.float32)
+        cnt, dim = nbrs.shape
+        vals = np.zeros((cnt, D), np.uint8)
+        aux = np.zeros((cnt, 3), np.float32)
+        pops = np.zeros((cnt, 2), np.uint32)
+        f = self._f("encode_edges")
+        f.argtypes = [C.c_int, C.c_int, C.c_int, f32p, f32p, C.c_int, u8p, f32p, u32p]
+        assert f(dim, D, bits, parent, nbrs, cnt, vals, aux, pops) == 0
+        return vals, aux, pops
+
     def dot(self, a, b):
         out = np.zeros(1, np.float32)
         f = self._f("dot")

@@ -97,3 +97,19 @@ def test_load_errors(oracle, tmp_path):
         oracle.load(str(p))
     with pytest.raises(RuntimeError, match="Cannot open"):
         oracle.load(str(tmp_path / "missing.idx"))
+
+
+ENC_SHAPES = ((10, 16), (50, 64), (96, 128), (128, 128), (300, 512), (960, 1024))
+
+
+@pytest.mark.parametrize("dim,D", ENC_SHAPES)
+@pytest.mark.parametrize("bits", [1, 2, 4])
+def test_edge_encoder(oracle, gold_build, dim, D, bits):
+    """Data-side encoder (per-edge RaBitQ / CAQ codes, nop, ip_qo, ip_cp, popcounts): the oracle's
+    restatement against what the reference computed, code values and float bits."""
+    k = f"ENC/{dim}/{D}/b{bits}"
+    for c in range(len(gold_build[f"{k}/parent"])):
+        v, a, s = oracle.encode_edges(gold_build[f"{k}/parent"][c], gold_build[f"{k}/nbrs"][c], D, bits)
+        assert np.array_equal(v, gold_build[f"{k}/values"][c])
+        assert _beq(a, gold_build[f"{k}/aux"][c])
+        assert np.array_equal(s, gold_build[f"{k}/pops"][c])
