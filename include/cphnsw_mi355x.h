@@ -66,9 +66,10 @@ int cph_dim(cph_index* h, uint64_t* dim);
 int cph_is_finalized(cph_index* h, int* flag);
 
 /* Index construction (api/hnsw_index.hpp:93-166).  build() copies the
- * n x dim float32 vectors; finalize() builds the graph (exact 32-NN on the GPU, alpha-CNG
- * pruning, per-edge RaBitQ codes, BFS reorder, upper layers, calibration).  Statistical, not
- * bit-level, parity with the reference's builder (which depends on its thread count). */
+ * n x dim float32 vectors; finalize() builds the index on the GPU (exact 32-NN on the matrix cores,
+ * reverse edges + neighbour selection, per-edge RaBitQ codes written straight into the search layout,
+ * upper layers, calibration sampling; csrc/builder.h).  The edge encoder is bit-exact with the
+ * reference's; the graph has statistical parity (the reference's own build depends on its thread count). */
 int cph_build(cph_index* h, const float* vectors, uint64_t n);
 int cph_finalize(cph_index* h);
 /* Construction / ground-truth hook: exact 32 nearest neighbours (squared L2, ascending) by brute
@@ -79,6 +80,13 @@ int cph_finalize(cph_index* h);
  * with fewer than 32 candidates are padded with 0xFFFFFFFF / FLT_MAX. */
 int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t dim, const float* queries,
                        uint64_t nq, uint32_t* ids, float* dist);
+
+/* Construction hook: the data-side encoder of one vertex' edges on the GPU (the kernel finalize() runs
+ * for every vertex; encoder/rabitq_encoder.hpp:138-181, 287-323, 371-467): parent and cnt <= 32
+ * neighbours (dim floats each) -> values u8[cnt][D] (code value per dimension), aux f32[cnt][3] =
+ * {nop, ip_qo, ip_cp}, pops u32[cnt][2] = {msb popcount, weighted popcount}. */
+int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* parent, const float* nbrs, uint64_t cnt,
+                     uint8_t* values, float* aux, uint32_t* pops);
 
 /* ---- search ---------------------------------------------------------------------- */
 /* queries: host, row-major [n][dim] float32.  ids/dist: host, [n][k], rows shorter than k

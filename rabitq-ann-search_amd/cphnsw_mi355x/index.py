@@ -234,6 +234,24 @@ def knn_bruteforce(vectors, queries=None, device=None):
     return ids, dist
 
 
+def encode_edges(parent, nbrs, bits, device=None):
+    """GPU data-side encoder of one vertex' edges (construction hook): (values u8[cnt, D], aux f32[cnt, 3] =
+    nop, ip_qo, ip_cp, pops u32[cnt, 2] = msb popcount, weighted popcount)."""
+    p = _as_f32(parent)
+    nb = _as_f32(nbrs)
+    cnt, dim = nb.shape
+    D = 16
+    while D < dim:
+        D *= 2
+    vals = np.zeros((cnt, D), np.uint8)
+    aux = np.zeros((cnt, 3), np.float32)
+    pops = np.zeros((cnt, 2), np.uint32)
+    dev = _default_device() if device is None else int(device)
+    _lib.check(_lib.lib().cph_encode_edges(dev, dim, int(bits), p.ctypes.data, nb.ctypes.data, cnt, vals.ctypes.data,
+                                           aux.ctypes.data, pops.ctypes.data))
+    return vals, aux, pops
+
+
 def _default_device():
     """One process per GPU: LOCAL_RANK selects the device when launched by torch.distributed.run."""
     import os

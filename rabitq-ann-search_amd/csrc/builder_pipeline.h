@@ -1,726 +1,475 @@
-// builder_pipeline.h — finalize(): layers, upper layers, GPU kNN, pruning, edge encoding, BFS
-// reorder, calibration.  See builder.h for scope and the deliberate differences.
+// builder_pipeline.h — finalize(): the construction pipeline of builder.h, stage by stage, and the
+// calibration that follows it.  See builder.h for the design and the reference citations.
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include <chrono>
-
 #include "builder.h"
-#include "device_knn.h"
 
 namespace cph {
 namespace build {
 
-struct Timer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    double lap() {
-        auto t1 = std::chrono::steady_clock::now();
-        double s = std::chrono::duration<double>(t1 - t0).count();
-        t0 = t1;
-        return s;
-    }
+struct BuiltDevice {            // the searchable index as the pipeline leaves it in HBM
+    DevBuf<uint8_t> blocks;     // [n][stride] device blocks
+    DevBuf<float> raw;          // [n][D] vectors, final order
+    DevBuf<float> norm;         // [n]
 };
 
-inline size_t isqrt_sz(size_t n) {
-    if (n < 2) return n;
-    size_t x = n, y = (x + 1) / 2;
-    while (y < x) { x = y; y = (x + n / x) / 2; }
-    return x;
+inline size_t isqrt_sz(size_t n) { return (size_t)std::floor(std::sqrt((double)n)); }
+
+template <int BW>
+inline void launch_encode(const EncodeArgsB& a, uint32_t grid, size_t lds) {
+    if (lds > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_edges_kernel<BW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(encode_edges_kernel<BW>, dim3(grid), dim3(64), lds, nullptr, a);
+    HIP_CHECK(hipGetLastError());
+}
+inline void launch_encode_bits(size_t bw, const EncodeArgsB& a, uint32_t grid, size_t lds) {
+    if (bw == 1) launch_encode<1>(a, grid, lds);
+    else if (bw == 2) launch_encode<2>(a, grid, lds);
+    else launch_encode<4>(a, grid, lds);
 }
 
-struct UpperBuilder {  // api/hnsw_index.hpp:476-716 on the pre-reorder ids
-    const float* raw; size_t D, n, M;
-    std::vector<int32_t>& levels;
-    std::vector<std::vector<UpperEdge>>& layers;
-    int max_level; uint32_t entry;
-    float tau = 0.0f, alpha = 1.2f;
-    std::vector<uint64_t> visit; uint64_t epoch = 0;
-
-    const float* vec(uint32_t i) const { return raw + (size_t)i * D; }
-    UpperEdge* find(int level, uint32_t node) {
-        auto& L = layers[level - 1];
-        auto it = std::lower_bound(L.begin(), L.end(), node, [](const UpperEdge& e, uint32_t v) { return e.node < v; });
-        return (it != L.end() && it->node == node) ? &*it : nullptr;
-    }
-    UpperEdge& get_or_create(int level, uint32_t node) {
-        auto& L = layers[level - 1];
-        auto it = std::lower_bound(L.begin(), L.end(), node, [](const UpperEdge& e, uint32_t v) { return e.node < v; });
-        if (it != L.end() && it->node == node) return *it;
-        return *L.insert(it, UpperEdge{node, {}});
-    }
-    uint32_t greedy(const float* q, uint32_t ep, int level) {
-        float best = l2sq(D, q, vec(ep));
-        uint32_t bid = ep;
-        bool improved = true;
-        while (improved) {
-            improved = false;
-            UpperEdge* e = find(level, bid);
-            if (!e) break;
-            for (uint32_t x : e->nbrs) {
-                float d = l2sq(D, q, vec(x));
-                if (d < best) { best = d; bid = x; improved = true; }
-            }
-        }
-        return bid;
-    }
-    std::vector<Cand> search_layer(const float* q, uint32_t ep, int level, size_t ef) {
-        auto gt = [](const Cand& a, const Cand& b) { return a.dist > b.dist; };
-        std::priority_queue<Cand, std::vector<Cand>, decltype(gt)> cands(gt);
-        std::priority_queue<Cand> nearest;
-        float epd = l2sq(D, q, vec(ep));
-        cands.push({ep, epd});
-        nearest.push({ep, epd});
-        ++epoch;
-        visit[ep] = epoch;
-        while (!cands.empty()) {
-            Cand cur = cands.top();
-            cands.pop();
-            if (nearest.size() >= ef && cur.dist > nearest.top().dist) break;
-            UpperEdge* e = find(level, cur.id);
-            if (!e) continue;
-            for (uint32_t x : e->nbrs) {
-                if (visit[x] == epoch) continue;
-                visit[x] = epoch;
-                float d = l2sq(D, q, vec(x));
-                if (nearest.size() < ef || d < nearest.top().dist) {
-                    cands.push({x, d});
-                    nearest.push({x, d});
-                    if (nearest.size() > ef) nearest.pop();
-                }
-            }
-        }
-        std::vector<Cand> res;
-        while (!nearest.empty()) { res.push_back(nearest.top()); nearest.pop(); }
-        std::sort(res.begin(), res.end());
-        return res;
-    }
-    void prune(uint32_t node, int level) {
-        auto& nb = get_or_create(level, node).nbrs;
-        if (nb.size() <= M) return;
-        std::vector<Cand> c;
-        for (uint32_t id : nb) c.push_back({id, l2sq(D, vec(node), vec(id))});
-        auto sel = select_alpha_cng(std::move(c), M, [&](uint32_t a, uint32_t b) { return l2sq(D, vec(a), vec(b)); },
-                                    [](uint32_t) { return 0.0f; }, alpha, tau);
-        auto& nb2 = get_or_create(level, node).nbrs;
-        nb2.clear();
-        for (auto& s : sel) nb2.push_back(s.id);
-    }
-    void run() {
-        const size_t R = 32;
-        std::vector<uint32_t> order(n);
-        std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return levels[a] > levels[b]; });
-        size_t n_upper = 0;
-        for (size_t i = 0; i < n; ++i) { if (levels[order[i]] > 0) ++n_upper; else break; }
-        visit.assign(n, 0);
-        size_t dist_samples = std::min(static_cast<size_t>(std::sqrt(static_cast<float>(n_upper)) * 10.0f), n_upper);
-        size_t nn_limit = std::min(dist_samples * 2, n_upper);
-        std::vector<float> nnd;
-        for (size_t idx = 0; idx < n && nnd.size() < dist_samples; ++idx) {
-            uint32_t node = order[idx];
-            if (levels[node] == 0) break;
-            float best = 3.402823466e+38f;
-            for (size_t j = 0; j < n && j < nn_limit; ++j) {
-                uint32_t o = order[j];
-                if (o == node) continue;
-                if (levels[o] == 0) break;
-                best = std::min(best, l2sq(D, vec(node), vec(o)));
-            }
-            if (best < 3.402823466e+38f) nnd.push_back(best);
-        }
-        if (!nnd.empty()) {
-            std::sort(nnd.begin(), nnd.end());
-            float med = nnd[nnd.size() / 2];
-            std::vector<float> ad(nnd.size());
-            for (size_t i = 0; i < nnd.size(); ++i) ad[i] = std::fabs(nnd[i] - med);
-            std::sort(ad.begin(), ad.end());
-            tau = 1.4826f * ad[ad.size() / 2];
-            float mean = 0;
-            for (float d : nnd) mean += d;
-            mean /= nnd.size();
-            float var = 0;
-            for (float d : nnd) var += (d - mean) * (d - mean);
-            var /= nnd.size();
-            alpha = 1.0f + (mean > kEpsSmall ? std::sqrt(var) / mean : 0.2f);
-        }
-        for (size_t idx = 0; idx < n; ++idx) {
-            uint32_t node = order[idx];
-            int nl = levels[node];
-            if (nl == 0) break;
-            uint32_t ep = entry;
-            for (int level = max_level; level > nl; --level) ep = greedy(vec(node), ep, level);
-            for (int level = std::min(nl, max_level); level >= 1; --level) {
-                size_t ef = std::clamp(
-                    static_cast<size_t>(static_cast<float>(R) *
-                                        (1.0f + static_cast<float>(level) *
-                                                    std::log(static_cast<float>(std::max(n_upper, size_t(2)))) /
-                                                    std::log(static_cast<float>(std::max(n, size_t(2)))))),
-                    R, R * 4);
-                auto cands = search_layer(vec(node), ep, level, ef);
-                auto sel = select_alpha_cng(std::move(cands), M,
-                                            [&](uint32_t a, uint32_t b) { return l2sq(D, vec(a), vec(b)); },
-                                            [](uint32_t) { return 0.0f; }, alpha, tau);
-                auto& mine = get_or_create(level, node).nbrs;
-                mine.clear();
-                for (auto& s : sel) mine.push_back(s.id);
-                for (auto& s : sel) {
-                    auto& nb = get_or_create(level, s.id).nbrs;
-                    nb.push_back(node);
-                    if (nb.size() > M) prune(s.id, level);
-                }
-                if (!sel.empty()) ep = sel[0].id;
-            }
-        }
-    }
-};
-
-// RAII device buffer for the construction kernels.
-template <class T>
-struct BuildBuf {
-    T* p = nullptr;
-    explicit BuildBuf(size_t count) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
-        if (e != hipSuccess) {
-            p = nullptr;
-            if (e == hipErrorOutOfMemory) throw std::bad_alloc();
-            throw std::runtime_error(std::string("HIP error in index construction: ") + hipGetErrorString(e));
-        }
-    }
-    ~BuildBuf() { if (p) (void)hipFree(p); }
-    BuildBuf(const BuildBuf&) = delete;
-    BuildBuf& operator=(const BuildBuf&) = delete;
-};
-inline void build_ck(hipError_t e) {
-    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in index construction: ") + hipGetErrorString(e));
-}
-
-// Exact 32-NN of query rows [0, nq) of d_q against base rows d_b, all device pointers; ascending by
-// distance.  Launched in slices of row blocks so that no single launch runs for minutes.
-// D must be a multiple of 32 (the kernel's K stage); narrower rows are zero-padded by the callers.
-inline void knn_device(const float* d_q, const float* d_qnorm, size_t nq, const float* d_b, const float* d_bnorm,
-                       size_t nb, size_t D, bool exclude_self, int num_cus, uint32_t* d_ids, float* d_dist) {
-    if (D % kKnnKC != 0 || nq == 0 || nb == 0) throw std::invalid_argument("knn_device: D must be a multiple of 32");
-    const uint32_t rows_per_launch = (uint32_t)num_cus * 8u * kKnnTile;
-    for (size_t rb = 0; rb < nq; rb += rows_per_launch) {
-        KnnArgs a{d_q, d_b, d_bnorm, d_qnorm, (uint32_t)nq, (uint32_t)nb, (uint32_t)D, (uint32_t)rb,
-                  (uint32_t)std::min<size_t>(nq, rb + rows_per_launch), exclude_self ? 1u : 0u, d_ids, d_dist};
-        const uint32_t grid = (a.row_end - a.row_begin + kKnnTile - 1) / kKnnTile;
-        hipLaunchKernelGGL(knn_mfma_kernel, dim3(grid), dim3(256), 0, nullptr, a);
-        build_ck(hipGetLastError());
-        build_ck(hipDeviceSynchronize());
-    }
-}
-
-// Host-pointer convenience: x[n][D] against itself (self excluded) or q[nq][D] against x[n][D].
-inline void gpu_knn(const float* q, const float* qnorm, size_t nq, const float* x, const float* norm_sq, size_t n,
-                    size_t D, int num_cus, uint32_t* out_ids, float* out_dist) {
-    const bool self = (q == nullptr);
-    const size_t Dk = (D + kKnnKC - 1) / kKnnKC * kKnnKC;      // D = 16 -> 32: zero columns
-    BuildBuf<float> d_x(n * Dk), d_norm(n), d_od((self ? n : nq) * kKnnK);
-    BuildBuf<uint32_t> d_oi((self ? n : nq) * kKnnK);
-    auto upload = [&](float* dst, const float* src, size_t rows) {
-        if (Dk == D) { build_ck(hipMemcpy(dst, src, rows * D * 4, hipMemcpyHostToDevice)); return; }
-        build_ck(hipMemset(dst, 0, rows * Dk * 4));
-        build_ck(hipMemcpy2D(dst, Dk * 4, src, D * 4, D * 4, rows, hipMemcpyHostToDevice));
-    };
-    upload(d_x.p, x, n);
-    build_ck(hipMemcpy(d_norm.p, norm_sq, n * 4, hipMemcpyHostToDevice));
-    if (self) {
-        knn_device(d_x.p, d_norm.p, n, d_x.p, d_norm.p, n, Dk, true, num_cus, d_oi.p, d_od.p);
-        nq = n;
-    } else {
-        BuildBuf<float> d_q(nq * Dk), d_qn(nq);
-        upload(d_q.p, q, nq);
-        build_ck(hipMemcpy(d_qn.p, qnorm, nq * 4, hipMemcpyHostToDevice));
-        knn_device(d_q.p, d_qn.p, nq, d_x.p, d_norm.p, n, Dk, false, num_cus, d_oi.p, d_od.p);
-    }
-    build_ck(hipMemcpy(out_ids, d_oi.p, nq * kKnnK * 4, hipMemcpyDeviceToHost));
-    build_ck(hipMemcpy(out_dist, d_od.p, nq * kKnnK * 4, hipMemcpyDeviceToHost));
-}
-
-// The whole finalize.  `vecs` = n x dim input rows.  Fills `hi` (reference-layout host index).
-inline void finalize_index(HostIndex& hi, const float* vecs, size_t n, size_t dim, size_t D, size_t bw,
-                           int num_cus, bool verbose) {
-    Timer tm;
-    auto note = [&](const char* what) { if (verbose) fprintf(stderr, "[build] %-28s %.2f s\n", what, tm.lap()); };
-    const size_t R = 32;
+// Graph, codes, upper layers.  `vecs` = n x dim input rows (host).  Fills `hi` (everything but the
+// calibration record) and `dev`.
+inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size_t n, size_t dim, size_t D, size_t bw,
+                        int num_cus, bool verbose) {
+    StageTimer tm{verbose};
+    const uint32_t R = 32;
     hi = HostIndex();
     hi.D = D; hi.bw = bw; hi.dim = dim; hi.n = n; hi.seed = 42;
     hi.RL = make_ref_layout(D, bw);
     hi.rot.init(D, 42);
-    const size_t M_UPPER = R / 2 + std::min(isqrt_sz(D) / 4, R / 4);
-    hi.mL = 1.0 / std::log(static_cast<double>(M_UPPER));
-    IndexProfile prof;
-    prof.n = n; prof.D = D; prof.R = R; prof.bits = bw;
-    prof.evt_min_tail = std::max<size_t>(64, static_cast<size_t>(std::sqrt(static_cast<double>(n))));
-    prof.min_calib_samples = std::clamp(static_cast<size_t>(10.0 * std::sqrt(static_cast<double>(n))), size_t(200), n);
+    const DevLayout L = make_dev_layout((uint32_t)D, (uint32_t)bw);
+    const size_t M_UPPER = R / 2 + std::min(isqrt_sz(D) / 4, (size_t)R / 4);      // api/hnsw_index.hpp:85
+    hi.mL = 1.0 / std::log((double)M_UPPER);
+    const size_t Dk = (D + kKnnKC - 1) / kKnnKC * kKnnKC;       // the kNN kernel's K stage (D = 16 -> 32)
+
+    // ---- vectors to HBM, norms, centroid ---------------------------------------------------------
+    DevBuf<float> d_x(n * D), d_norm(n);
+    upload_padded(d_x.p, D, vecs, dim, n);
+    hipLaunchKernelGGL(row_norms_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nullptr, d_x.p, (uint64_t)n, (uint32_t)D,
+                       (uint32_t)dim, d_norm.p);
+    HIP_CHECK(hipGetLastError());
+    std::vector<float> centroid(dim);
+    DevBuf<float> d_centroid(D);
     {
-        float log_n = std::log2(static_cast<float>(std::max(n, size_t(64))));
-        prof.slack_levels = std::clamp(static_cast<int>(std::ceil(std::log2(std::max(10.0f * log_n, 4.0f)))), 4, 32);
+        DevBuf<double> d_cs(dim);
+        HIP_CHECK(hipMemset(d_cs.p, 0, dim * 8));
+        hipLaunchKernelGGL(column_sums_kernel, dim3((uint32_t)std::min<size_t>(1024, std::max<size_t>(1, n / 256))), dim3(256), 0,
+                           nullptr, d_x.p, (uint64_t)n, (uint32_t)D, (uint32_t)dim, d_cs.p);
+        HIP_CHECK(hipGetLastError());
+        std::vector<double> cs(dim);
+        HIP_CHECK(hipMemcpy(cs.data(), d_cs.p, dim * 8, hipMemcpyDeviceToHost));
+        std::vector<float> padded(D, 0.0f);
+        for (size_t j = 0; j < dim; ++j) padded[j] = centroid[j] = (float)(cs[j] / (double)n);
+        HIP_CHECK(hipMemcpy(d_centroid.p, padded.data(), D * 4, hipMemcpyHostToDevice));
     }
+    tm.lap("upload, norms, centroid");
 
-    // ---- vectors, norms, centroid, own codes (graph/rabitq_graph.hpp:73-92; encoder :42-71,225-262,326-352)
-    std::vector<float> raw(n * D, 0.0f), norm_sq(n);
-    parallel_for(n, 1024, [&](size_t lo, size_t hi_) {
-        for (size_t i = lo; i < hi_; ++i) {
-            std::memcpy(&raw[i * D], vecs + i * dim, dim * 4);
-            float s = 0.0f;
-            for (size_t j = 0; j < dim; ++j) s = std::fmaf(raw[i * D + j], raw[i * D + j], s);
-            norm_sq[i] = s;
-        }
-    });
-    std::vector<float> centroid(dim, 0.0f);
-    for (size_t i = 0; i < n; ++i)
-        for (size_t j = 0; j < dim; ++j) centroid[j] += vecs[i * dim + j];
-    for (size_t j = 0; j < dim; ++j) centroid[j] *= 1.0f / static_cast<float>(n);
-    DataEncoder enc;
-    enc.init(&hi.rot, D, dim, bw);
-    std::vector<uint8_t> search(n * hi.RL.vertex_bytes, 0);
-    std::vector<float> own_nop(n);
-    const size_t words = (D + 63) / 64;
-    const size_t code_meta = round_up(bw * words * 8, 64);
-    parallel_for(n, 256, [&](size_t lo, size_t hi_) {
-        std::vector<float> c(D), rot(D);
-        std::vector<int> codes;
-        EdgeCode e;
-        for (size_t i = lo; i < hi_; ++i) {
-            float ns = 0.0f;
-            for (size_t j = 0; j < dim; ++j) { c[j] = vecs[i * dim + j] - centroid[j]; ns += c[j] * c[j]; }
-            for (size_t j = dim; j < D; ++j) c[j] = 0.0f;
-            const float nrm = std::sqrt(ns);
-            own_nop[i] = nrm;
-            uint8_t* v = &search[i * hi.RL.vertex_bytes];
-            float ipqo = 0.0f;
-            if (!(nrm < 1e-8f / static_cast<float>(D))) {
-                for (size_t j = 0; j < dim; ++j) c[j] *= 1.0f / nrm;
-                enc.rotate_scaled(c.data(), rot.data());
-                enc.quantize(rot.data(), nullptr, e, codes);
-                ipqo = e.ip_qo;
-                for (size_t b = 0; b < bw; ++b)
-                    for (size_t d = 0; d < D; ++d)
-                        if ((e.u[d] >> (bw - 1 - b)) & 1) v[(b * words + d / 64) * 8 + (d % 64) / 8] |= (uint8_t)(1u << (d % 8));
-            }
-            std::memcpy(v + code_meta, &nrm, 4);
-            std::memcpy(v + code_meta + 4, &ipqo, 4);
-        }
-    });
-    note("vectors + own codes");
-
-    // ---- layers (api/hnsw_index.hpp:484-503) + upper layers (:505-615)
+    // ---- layer of every vertex: floor(-ln(U) mL), one mt19937_64(42) stream (api/hnsw_index.hpp:484-503) ----
     std::vector<int32_t> levels(n);
     int max_level = 0;
-    uint32_t entry = kInvalidNode;
+    uint32_t entry_old = kInvalidNode;
     {
         std::mt19937_64 rng(42);
-        std::uniform_real_distribution<double> dist(0.0, 1.0);
+        std::uniform_real_distribution<double> uni(0.0, 1.0);
         for (size_t i = 0; i < n; ++i) {
-            double r = dist(rng);
-            if (r < 1e-15) r = 1e-15;
-            int level = static_cast<int>(-std::log(r) * hi.mL);
-            levels[i] = level;
-            if (entry == kInvalidNode || level > max_level) { max_level = level; entry = (uint32_t)i; }
+            const double r = std::max(uni(rng), 1e-15);
+            const int lv = (int)(-std::log(r) * hi.mL);
+            levels[i] = lv;
+            if (entry_old == kInvalidNode || lv > max_level) { max_level = lv; entry_old = (uint32_t)i; }
         }
     }
-    std::vector<std::vector<UpperEdge>> layers(max_level);
-    UpperBuilder ub{raw.data(), D, n, M_UPPER, levels, layers, max_level, entry, 0.0f, 1.2f, {}, 0};
-    ub.run();
-    note("upper layers");
 
-    // ---- exact 32-NN working lists on the GPU (replaces NNDescent) ------------------------
-    std::vector<uint32_t> knn_ids(n * kKnnK);
-    std::vector<float> knn_d(n * kKnnK);
-    gpu_knn(nullptr, nullptr, 0, raw.data(), norm_sq.data(), n, D, num_cus, knn_ids.data(), knn_d.data());
-    note("GPU exact 32-NN");
-
-    auto vec = [&](uint32_t i) { return &raw[(size_t)i * D]; };
-    // ---- graph statistics (graph_refinement.hpp:266-383) on the working lists ---------------
-    GraphStats gs{};
+    // ---- exact 32-NN lists on the matrix cores ----------------------------------------------------------
+    DevBuf<uint32_t> d_knn(n * kKnnK);
     {
-        size_t sample = std::min(static_cast<size_t>(std::sqrt(static_cast<double>(n))), n);
+        DevBuf<float> d_kd(n * kKnnK);
+        if (Dk == D) {
+            knn_device(d_x.p, d_norm.p, n, d_x.p, d_norm.p, n, D, true, num_cus, d_knn.p, d_kd.p);
+        } else {
+            DevBuf<float> d_xk(n * Dk);
+            HIP_CHECK(hipMemset(d_xk.p, 0, n * Dk * 4));
+            HIP_CHECK(hipMemcpy2D(d_xk.p, Dk * 4, d_x.p, D * 4, D * 4, n, hipMemcpyDeviceToDevice));
+            knn_device(d_xk.p, d_norm.p, n, d_xk.p, d_norm.p, n, Dk, true, num_cus, d_knn.p, d_kd.p);
+        }
+    }
+    tm.lap("exact 32-NN (MFMA)");
+
+    // ---- pruning parameters from a sample of the lists (graph_refinement.hpp:266-383's statistics) ---------
+    GraphStatsRecord gs{};
+    {
+        const size_t sample = std::max<size_t>(1, std::min(isqrt_sz(n), n));
         std::mt19937 rng(43);
-        std::vector<size_t> idx(n);
-        std::iota(idx.begin(), idx.end(), 0);
-        std::shuffle(idx.begin(), idx.end(), rng);
-        idx.resize(sample);
-        std::vector<float> nd, ind, nnd;
-        float total_deg = 0.0f;
-        for (size_t i = 0; i < n; ++i) {
-            uint32_t c = 0;
-            for (int s = 0; s < kKnnK; ++s) c += knn_ids[i * kKnnK + s] != kInvalidNode;
-            total_deg += (float)c;
+        std::vector<size_t> pick(n);
+        std::iota(pick.begin(), pick.end(), 0);
+        std::shuffle(pick.begin(), pick.end(), rng);
+        pick.resize(sample);
+        auto dist = [&](uint32_t a, uint32_t b) {
+            double s = 0;
+            for (size_t j = 0; j < dim; ++j) { const double t = (double)vecs[(size_t)a * dim + j] - vecs[(size_t)b * dim + j]; s += t * t; }
+            return (float)s;
+        };
+        const size_t pairs_of = std::clamp((size_t)(2.0 * std::sqrt((double)R)), (size_t)4, (size_t)R);
+        std::vector<float> edge_len, first_len, between;
+        std::vector<uint32_t> row(kKnnK);
+        double deg = 0;
+        for (size_t v : pick) {
+            HIP_CHECK(hipMemcpy(row.data(), d_knn.p + v * kKnnK, kKnnK * 4, hipMemcpyDeviceToHost));
+            size_t c = 0;
+            while (c < (size_t)kKnnK && row[c] != kInvalidNode) ++c;
+            deg += (double)c;
+            for (size_t s = 0; s < c; ++s) edge_len.push_back(dist((uint32_t)v, row[s]));
+            if (c) first_len.push_back(edge_len[edge_len.size() - c]);
+            const size_t m = std::min(c, pairs_of);
+            for (size_t i = 0; i < m; ++i)
+                for (size_t j = i + 1; j < m; ++j) between.push_back(dist(row[i], row[j]));
         }
-        gs.avg_degree = total_deg / static_cast<float>(std::max(n, size_t(1)));
-        const size_t inter_limit = std::clamp(static_cast<size_t>(2.0 * std::sqrt(static_cast<double>(R))), size_t(4), R);
-        for (size_t i : idx) {
-            const uint32_t* w = &knn_ids[i * kKnnK];
-            const float* wd = &knn_d[i * kKnnK];
-            size_t cnt = 0;
-            while (cnt < (size_t)kKnnK && w[cnt] != kInvalidNode) ++cnt;
-            for (size_t s = 0; s < cnt; ++s) nd.push_back(wd[s]);
-            if (cnt) nnd.push_back(wd[0]);
-            const size_t il = std::min(cnt, inter_limit);
-            for (size_t j = 0; j < il; ++j)
-                for (size_t k = j + 1; k < il; ++k) ind.push_back(l2sq(D, vec(w[j]), vec(w[k])));
-        }
-        if (nd.empty() || ind.empty() || nnd.empty()) { gs.alpha = 1.0f; gs.tau = 0.0f; gs.alpha_max = 4.0f; }
-        else {
-            std::sort(nd.begin(), nd.end()); std::sort(ind.begin(), ind.end()); std::sort(nnd.begin(), nnd.end());
-            const float neps = 1e-8f / static_cast<float>(D);
-            const float med = nd[nd.size() / 2], q1 = nd[nd.size() / 4], q3 = nd[3 * nd.size() / 4];
-            const float q3q1 = q1 > neps ? q3 / q1 : 2.0f;
-            float mean = 0; for (float d : nd) mean += d; mean /= nd.size();
-            float var = 0; for (float d : nd) var += (d - mean) * (d - mean); var /= nd.size();
-            const float cv = mean > neps ? std::sqrt(var) / mean : 0.2f;
-            const float nnm = nnd[nnd.size() / 2];
-            std::vector<float> ad(nnd.size());
-            for (size_t i = 0; i < nnd.size(); ++i) ad[i] = std::fabs(nnd[i] - nnm);
-            std::sort(ad.begin(), ad.end());
-            const float d_inter = ind[ind.size() / 4];
-            gs.alpha = d_inter < neps ? 1.0f + cv : med / d_inter;
-            gs.alpha_max = std::min(q3q1, 5.0f);
+        gs.avg_degree = (float)(deg / (double)pick.size());
+        if (edge_len.empty() || between.empty() || first_len.empty()) {
+            gs.alpha = 1.0f; gs.tau = 0.0f; gs.alpha_max = 4.0f;
+        } else {
+            std::sort(edge_len.begin(), edge_len.end());
+            std::sort(between.begin(), between.end());
+            const float tiny = 1e-8f / (float)D;
+            const float med = quantile_sorted(edge_len, 1, 2), q1 = quantile_sorted(edge_len, 1, 4), q3 = quantile_sorted(edge_len, 3, 4);
+            double mu = 0, var = 0;
+            for (float d : edge_len) mu += d;
+            mu /= edge_len.size();
+            for (float d : edge_len) var += (d - mu) * (d - mu);
+            var /= edge_len.size();
+            const float cv = mu > tiny ? (float)(std::sqrt(var) / mu) : 0.2f;
+            const float inter = quantile_sorted(between, 1, 4);
+            // alpha: typical edge length over the lower-quartile distance BETWEEN a vertex' neighbours; its
+            // ceiling from the spread of the edge lengths; tau: robust scale of the nearest-neighbour distances
+            gs.alpha = inter < tiny ? 1.0f + cv : med / inter;
+            gs.alpha_max = std::min(q1 > tiny ? q3 / q1 : 2.0f, 5.0f);
             gs.alpha = std::clamp(gs.alpha, 1.0f, gs.alpha_max);
             gs.alpha_max = std::max(gs.alpha_max, 2.0f * gs.alpha);
-            gs.tau = 1.4826f * ad[ad.size() / 2];
+            gs.tau = mad_sigma(first_len, median_of(first_len));
         }
     }
-    prof.graph_stats = gs;
 
-    // ---- first pass keeps the working lists (<= R candidates: no pruning, :535-536), then the
-    // reverse-edge pass (:386-429) prunes own + reverse candidates with alpha-CNG ------------
-    const float err_tol = 1.0f / std::sqrt(static_cast<float>(D));
-    // exact edge lengths in the reference's summation order (the GPU distances served only to rank)
-    parallel_for(n, 256, [&](size_t lo, size_t hi_) {
-        for (size_t u = lo; u < hi_; ++u)
-            for (int s = 0; s < kKnnK; ++s) {
-                const uint32_t v = knn_ids[u * kKnnK + s];
-                if (v != kInvalidNode) knn_d[u * kKnnK + s] = l2sq(D, vec((uint32_t)u), vec(v));
-            }
-    });
-    std::vector<std::vector<Cand>> rev(n);
+    // ---- layer 0: reverse edges + selection on the GPU --------------------------------------------------
+    DevBuf<uint32_t> d_nbr(n * 32), d_cnt(n);
     {
-        std::vector<uint32_t> indeg(n, 0);
-        for (size_t e = 0; e < n * (size_t)kKnnK; ++e)
-            if (knn_ids[e] != kInvalidNode) ++indeg[knn_ids[e]];
-        for (size_t v = 0; v < n; ++v) rev[v].reserve(indeg[v]);
+        DevBuf<float> d_err(n);
+        const float err_tol = 1.0f / std::sqrt((float)D);
+        hipLaunchKernelGGL(centered_norm_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nullptr, d_x.p, d_centroid.p, (uint64_t)n,
+                           (uint32_t)D, (uint32_t)dim, err_tol, d_err.p);
+        HIP_CHECK(hipGetLastError());
+        LayerParams lp{R, gs.alpha, gs.tau, gs.alpha_max, d_err.p};
+        select_layer(d_x.p, D, d_knn.p, n, nullptr, lp, num_cus, d_nbr.p, d_cnt.p);
     }
-    for (size_t u = 0; u < n; ++u)
-        for (int s = 0; s < kKnnK; ++s) {
-            const uint32_t v = knn_ids[u * kKnnK + s];
-            if (v == kInvalidNode) continue;
-            rev[v].push_back({(uint32_t)u, knn_d[u * kKnnK + s]});
-        }
-    std::vector<uint32_t> nbr(n * R, kInvalidNode);
-    std::vector<uint8_t> nbr_cnt(n, 0);
-    parallel_for(n, 64, [&](size_t lo, size_t hi_) {
-        for (size_t i = lo; i < hi_; ++i) {
-            std::vector<Cand> all;
-            for (int s = 0; s < kKnnK; ++s) {
-                const uint32_t w = knn_ids[i * kKnnK + s];
-                if (w == kInvalidNode) continue;
-                all.push_back({w, knn_d[i * kKnnK + s]});
-            }
-            std::vector<Cand> sel;
-            if (rev[i].empty()) {
-                sel = all;  // untouched by the reverse pass: the first-pass list stands
-                std::sort(sel.begin(), sel.end());
-            } else {
-                for (const auto& c : rev[i]) if (c.id != i) all.push_back(c);
-                sel = select_alpha_cng(std::move(all), R,
-                                       [&](uint32_t a, uint32_t b) { return l2sq(D, vec(a), vec(b)); },
-                                       [&](uint32_t x) { return err_tol * own_nop[x]; }, gs.alpha, gs.tau, gs.alpha_max);
-            }
-            nbr_cnt[i] = (uint8_t)std::min<size_t>(sel.size(), R);
-            for (size_t j = 0; j < nbr_cnt[i]; ++j) nbr[i * R + j] = sel[j].id;
-        }
-    });
-    { std::vector<std::vector<Cand>>().swap(rev); }
-    note("stats + reverse pass + prune");
+    d_knn.release();
+    tm.lap("reverse edges + selection");
 
-    // ---- encode every edge into the reference-layout blocks (prune_and_write, :30-68) ---------
-    parallel_for(n, 64, [&](size_t lo, size_t hi_) {
-        std::vector<float> rp(D), tmp;
-        std::vector<int> codes;
-        EdgeCode e;
-        for (size_t i = lo; i < hi_; ++i) {
-            uint8_t* nb = &search[i * hi.RL.vertex_bytes + hi.RL.nb_off];
-            std::memset(nb + hi.RL.ids, 0xFF, 128);
-            enc.rotate_scaled(vec((uint32_t)i), rp.data());
-            const uint32_t cnt = nbr_cnt[i];
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t v = nbr[i * R + j];
-                enc.encode_edge(vec((uint32_t)i), vec(v), rp.data(), e, tmp, codes);
-                write_slot(nb, hi.RL, D, bw, j, v, e);
-            }
-            std::memcpy(nb + hi.RL.count, &cnt, 4);
-        }
-    });
-    note("edge encoding");
-
-    // ---- hub entry (rabitq_graph.hpp:303-340) and BFS reorder (:208-278) --------------------
-    std::vector<double> cen(dim, 0.0);
-    for (size_t i = 0; i < n; ++i)
-        for (size_t j = 0; j < dim; ++j) cen[j] += raw[i * D + j];
-    for (size_t j = 0; j < dim; ++j) cen[j] *= 1.0 / static_cast<double>(n);
-    uint32_t hub = 0;
-    {
-        struct CD { uint32_t id; double d; };
-        std::vector<CD> cd(n);
-        for (size_t i = 0; i < n; ++i) {
-            double s = 0;
-            for (size_t j = 0; j < dim; ++j) { double t = raw[i * D + j] - cen[j]; s += t * t; }
-            cd[i] = {(uint32_t)i, s};
-        }
-        size_t top = std::max<size_t>(1, static_cast<size_t>(std::sqrt(static_cast<double>(n))));
-        if (top < n) std::partial_sort(cd.begin(), cd.begin() + top, cd.end(), [](const CD& a, const CD& b) { return a.d < b.d; });
-        uint32_t best = kInvalidNode;
-        size_t bdeg = 0;
-        for (size_t i = 0; i < top && i < n; ++i)
-            if (best == kInvalidNode || nbr_cnt[cd[i].id] > bdeg) { bdeg = nbr_cnt[cd[i].id]; best = cd[i].id; }
-        hub = best;
-    }
+    // ---- hub and BFS renumbering (host: a queue walk) -----------------------------------------------------
+    std::vector<uint32_t> nbr(n * 32), cnt(n);
+    HIP_CHECK(hipMemcpy(nbr.data(), d_nbr.p, n * 32 * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(cnt.data(), d_cnt.p, n * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> old_to_new(n, kInvalidNode), new_to_old(n);
     {
+        // hub: among the sqrt(n) vertices nearest the centroid, the one with the most edges
+        std::vector<std::pair<double, uint32_t>> near(n);
+        parallel_for(n, 4096, [&](size_t lo, size_t hi_) {
+            for (size_t i = lo; i < hi_; ++i) {
+                double s = 0;
+                for (size_t j = 0; j < dim; ++j) { const double t = (double)vecs[i * dim + j] - centroid[j]; s += t * t; }
+                near[i] = {s, (uint32_t)i};
+            }
+        });
+        const size_t top = std::min(n, std::max<size_t>(1, isqrt_sz(n)));
+        std::partial_sort(near.begin(), near.begin() + top, near.end());
+        uint32_t hub = near[0].second;
+        for (size_t i = 1; i < top; ++i)
+            if (cnt[near[i].second] > cnt[hub]) hub = near[i].second;
         std::vector<uint8_t> seen(n, 0);
-        std::queue<uint32_t> q;
+        std::vector<uint32_t> queue;
+        queue.reserve(n);
         uint32_t next = 0;
-        auto bfs = [&](uint32_t s) {
-            if (s >= n || seen[s]) return;
-            q.push(s); seen[s] = 1;
-            while (!q.empty()) {
-                uint32_t c = q.front(); q.pop();
-                old_to_new[c] = next; new_to_old[next] = c; ++next;
-                for (uint32_t j = 0; j < nbr_cnt[c]; ++j) {
-                    uint32_t v = nbr[c * R + j];
-                    if (v != kInvalidNode && v < n && !seen[v]) { seen[v] = 1; q.push(v); }
+        auto walk = [&](uint32_t start) {
+            if (seen[start]) return;
+            seen[start] = 1;
+            queue.push_back(start);
+            for (size_t head = queue.size() - 1; head < queue.size(); ++head) {
+                const uint32_t v = queue[head];
+                old_to_new[v] = next;
+                new_to_old[next++] = v;
+                for (uint32_t j = 0; j < cnt[v]; ++j) {
+                    const uint32_t w = nbr[(size_t)v * 32 + j];
+                    if (w < n && !seen[w]) { seen[w] = 1; queue.push_back(w); }
                 }
             }
         };
-        bfs(hub);
-        for (size_t i = 0; i < n; ++i) if (!seen[i]) bfs((uint32_t)i);
+        walk(hub);
+        for (size_t i = 0; i < n; ++i) walk((uint32_t)i);
     }
-    hi.raw.resize(n * D); hi.norm_sq.resize(n); hi.search_data.resize(n * hi.RL.vertex_bytes); hi.levels.resize(n);
-    parallel_for(n, 1024, [&](size_t lo, size_t hi_) {
-        for (size_t nw = lo; nw < hi_; ++nw) {
-            const uint32_t od = new_to_old[nw];
-            std::memcpy(&hi.raw[nw * D], &raw[(size_t)od * D], D * 4);
-            hi.norm_sq[nw] = norm_sq[od];
-            hi.levels[nw] = levels[od];
-            uint8_t* dst = &hi.search_data[nw * hi.RL.vertex_bytes];
-            std::memcpy(dst, &search[(size_t)od * hi.RL.vertex_bytes], hi.RL.vertex_bytes);
-            uint32_t* ids = reinterpret_cast<uint32_t*>(dst + hi.RL.nb_off + hi.RL.ids);
-            for (int j = 0; j < 32; ++j)
-                if (ids[j] != kInvalidNode && ids[j] < n) ids[j] = old_to_new[ids[j]];
-        }
-    });
-    for (auto& layer : layers) {
-        for (auto& e : layer) {
-            e.node = old_to_new[e.node];
-            for (auto& x : e.nbrs) x = old_to_new[x];
-        }
-        std::sort(layer.begin(), layer.end(), [](const UpperEdge& a, const UpperEdge& b) { return a.node < b.node; });
-    }
-    hi.upper = std::move(layers);
-    hi.max_level = max_level;
-    hi.entry = old_to_new[entry];
-    hi.upper_tau = ub.tau;
-    hi.upper_alpha = ub.alpha;
-    hi.centroid = centroid;
-    { std::vector<float>().swap(raw); std::vector<uint8_t>().swap(search); }
-    note("hub + BFS reorder");
+    tm.lap("hub + BFS order");
 
-    // ---- estimator calibration (api/hnsw_index.hpp:718-1139) ----------------------------------
-    CalibrationSnapshot cal{};
+    // ---- final order in HBM: vectors, norms, neighbour lists ------------------------------------------------
+    DevBuf<uint32_t> d_o2n(n), d_n2o(n);
+    HIP_CHECK(hipMemcpy(d_o2n.p, old_to_new.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_n2o.p, new_to_old.data(), n * 4, hipMemcpyHostToDevice));
+    dev.raw.alloc(n * D);
+    dev.norm.alloc(n);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)std::min<uint64_t>(n, (uint64_t)num_cus * 64)), dim3(64), 0, nullptr,
+                       d_x.p, d_n2o.p, (uint64_t)n, (uint32_t)D, dev.raw.p);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nullptr, d_norm.p, d_n2o.p, (uint64_t)n, dev.norm.p);
+    HIP_CHECK(hipGetLastError());
+    DevBuf<uint32_t> d_nbr_new(n * 32);
+    hipLaunchKernelGGL(permute_lists_kernel, dim3(grid_for(n * 32, 256)), dim3(256), 0, nullptr, d_nbr.p, d_n2o.p, d_o2n.p,
+                       (uint64_t)n, d_nbr_new.p);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    d_x.release(); d_norm.release(); d_nbr.release(); d_cnt.release();
+
+    // ---- codes: every edge into the device blocks, every vertex' own code for the file ----------------------
+    DevBuf<float> d_signs(3 * D);
+    HIP_CHECK(hipMemcpy(d_signs.p, hi.rot.signs.data(), 3 * D * 4, hipMemcpyHostToDevice));
+    const float df = (float)D;
+    const float norm_factor = 1.0f / (df * std::sqrt(df)), inv_sqrt_d = 1.0f / std::sqrt(df);
+    dev.blocks.alloc(n * L.stride + 64);
+    HIP_CHECK(hipMemset(dev.blocks.p, 0, n * L.stride + 64));
+    const size_t words = (D + 63) / 64;
+    const uint32_t own_meta = (uint32_t)round_up(bw * words * 8, 64);
+    const uint32_t own_stride = (uint32_t)hi.RL.nb_off;            // the vertex header in front of the neighbour block
+    DevBuf<uint8_t> d_own(n * own_stride);
+    HIP_CHECK(hipMemset(d_own.p, 0, n * own_stride));
     {
-        const size_t num_samples = std::min(prof.min_calib_samples, n);
-        if (n < 50) throw std::runtime_error("Calibration requires at least 50 nodes.");
-        std::vector<uint32_t> sid(n);
-        std::iota(sid.begin(), sid.end(), 0u);
-        std::mt19937 rng(static_cast<uint32_t>(42 + 99999));
-        std::shuffle(sid.begin(), sid.end(), rng);
-        const size_t n_db = std::min(num_samples, n), n_synth = std::min(num_samples / 2, n);
-        std::vector<float> dim_var(D, 0.0f), dim_mean(D, 0.0f);
-        const size_t var_sample = std::min(n, num_samples / 4);
-        for (size_t i = 0; i < var_sample; ++i) {
-            const float* v = hi.vec(sid[i]);
-            for (size_t d = 0; d < D; ++d) { dim_var[d] += v[d] * v[d]; dim_mean[d] += v[d]; }
-        }
-        for (size_t d = 0; d < D; ++d) {
-            dim_mean[d] /= static_cast<float>(var_sample);
-            dim_var[d] = dim_var[d] / static_cast<float>(var_sample) - dim_mean[d] * dim_mean[d];
-            if (dim_var[d] < kEpsSmall) dim_var[d] = kEpsSmall;
-        }
-        struct CS { float nop, ipc, ipq, dqp; uint32_t nbr; size_t qi; };
-        std::vector<float> ipqo_vals, ps_ipc, ps_ipq, truths, nn_d, nops;
-        std::vector<CS> cs;
-        std::vector<std::vector<float>> qbuf;
-        size_t cursor = 0;
-        std::vector<float> work(D);
-        EncodedQuery eq;
-        auto process = [&](const float* q, size_t qi) {
-            uint32_t parent = sid[cursor % n];
-            ++cursor;
-            float best = l2sq(D, q, hi.vec(parent));
-            {
-                const uint8_t* nb = hi.nb(parent);
-                uint32_t cnt; std::memcpy(&cnt, nb + hi.RL.count, 4);
-                const uint32_t* ids = reinterpret_cast<const uint32_t*>(nb + hi.RL.ids);
-                const uint32_t p0 = parent;
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    if (ids[i] == kInvalidNode) break;
-                    float d = l2sq(D, q, hi.vec(ids[i]));
-                    if (d < best) { best = d; parent = ids[i]; }
-                }
-                (void)p0;
-            }
-            nn_d.push_back(best);
-            const uint8_t* pnb = hi.nb(parent);
-            uint32_t pcnt; std::memcpy(&pcnt, pnb + hi.RL.count, 4);
-            std::memcpy(work.data(), q, D * 4);
-            encode_query(hi.rot, work.data(), eq);
-            const float dqp = l2sq(D, q, hi.vec(parent));
-            uint32_t sums[32];
-            host_block_sums(pnb, hi.RL, D, bw, eq.qu.data(), sums);
-            const uint32_t* ids = reinterpret_cast<const uint32_t*>(pnb + hi.RL.ids);
-            const float* nopa = reinterpret_cast<const float*>(pnb + hi.RL.nop);
-            const float* ipqa = reinterpret_cast<const float*>(pnb + hi.RL.ip_qo);
-            const float* ipca = reinterpret_cast<const float*>(pnb + hi.RL.ip_cp);
-            const uint16_t* popa = reinterpret_cast<const uint16_t*>(pnb + hi.RL.pop);
-            const uint16_t* wpopa = bw > 1 ? reinterpret_cast<const uint16_t*>(pnb + hi.RL.wpop) : nullptr;
-            const float K = static_cast<float>((1u << bw) - 1), invK = 1.0f / K;
-            for (uint32_t j = 0; j < pcnt && j < 32; ++j) {
-                const uint32_t nbid = ids[j];
-                if (nbid == kInvalidNode) break;
-                const float ipqo = ipqa[j];
-                ipqo_vals.push_back(ipqo);
-                const float nop = std::max(nopa[j], kEpsSmall);
-                nops.push_back(nop);
-                float ipa;
-                if (bw == 1) ipa = eq.A * static_cast<float>(sums[j]) + eq.B * static_cast<float>(popa[j]) + eq.C;
-                else ipa = eq.A * invK * static_cast<float>(sums[j]) + eq.B * invK * static_cast<float>(wpopa[j]) + eq.C;
-                const float ipc = ipa - ipca[j];
-                const float ipq = std::max(std::fabs(ipqo), kEpsMedium);
-                const float* pv = hi.vec(parent);
-                const float* ov = hi.vec(nbid);
-                float tip = 0.0f;
-                for (size_t d = 0; d < D; ++d) tip += (q[d] - pv[d]) * (ov[d] - pv[d]);
-                tip /= nop;
-                ps_ipc.push_back(ipc); ps_ipq.push_back(ipq); truths.push_back(tip);
-                cs.push_back({nop, ipc, ipq, dqp, nbid, qi});
-            }
-        };
-        for (size_t i = 0; i < n_db; ++i) {
-            qbuf.emplace_back(hi.vec(sid[i]), hi.vec(sid[i]) + D);
-            process(qbuf.back().data(), qbuf.size() - 1);
-        }
-        std::normal_distribution<float> nd(0.0f, 1.0f);
-        for (size_t i = 0; i < n_synth; ++i) {
-            const float* base = hi.vec(sid[i % n]);
-            std::vector<float> sq(D);
-            for (size_t d = 0; d < D; ++d) sq[d] = base[d] + nd(rng) * std::sqrt(dim_var[d]);
-            qbuf.push_back(std::move(sq));
-            process(qbuf.back().data(), qbuf.size() - 1);
-        }
-        if (ipqo_vals.empty()) throw std::runtime_error("Calibration failed: no ip_qo samples.");
-        std::sort(ipqo_vals.begin(), ipqo_vals.end());
-        {
-            const float med = ipqo_vals[ipqo_vals.size() / 2];
-            std::vector<float> ad(ipqo_vals.size());
-            for (size_t i = 0; i < ad.size(); ++i) ad[i] = std::fabs(ipqo_vals[i] - med);
-            std::sort(ad.begin(), ad.end());
-            cal.ip_qo_floor = std::max(med - 3.0f * 1.4826f * ad[ad.size() / 2], kEpsMedium);
-        }
-        std::vector<float> fe(ps_ipc.size());
-        for (size_t i = 0; i < fe.size(); ++i) fe[i] = ps_ipc[i] / std::max(ps_ipq[i], cal.ip_qo_floor);
-        if (fe.size() < 20) throw std::runtime_error("Calibration failed: too few estimator/target pairs.");
-        const size_t np = fe.size();
-        double se = 0, stt = 0, see = 0, set_ = 0;
-        for (size_t i = 0; i < np; ++i) { double e = fe[i], t = truths[i]; se += e; stt += t; see += e * e; set_ += e * t; }
-        const double me = se / np, mt = stt / np, ve = see / np - me * me, cov = set_ / np - me * mt;
-        double a = 1.0, b = 0.0;
-        if (ve > kEpsSmall) { a = cov / ve; b = mt - a * me; }
-        std::vector<float> ar(np);
-        for (int iter = 0; iter < 10; ++iter) {  // Huber IRLS, :946-985
-            for (size_t i = 0; i < np; ++i) ar[i] = std::fabs(truths[i] - static_cast<float>(a * fe[i] + b));
-            std::sort(ar.begin(), ar.end());
-            const float hd = 1.345f * 1.4826f * ar[np / 2];
-            if (hd < kEpsSmall) break;
-            double w0 = 0, we = 0, wt = 0, wee = 0, wet = 0;
-            for (size_t i = 0; i < np; ++i) {
-                const float r = std::fabs(truths[i] - static_cast<float>(a * fe[i] + b));
-                const double w = (r <= hd) ? 1.0 : (double)(hd / r);
-                const double e = fe[i], t = truths[i];
-                w0 += w; we += w * e; wt += w * t; wee += w * e * e; wet += w * e * t;
-            }
-            const double wme = we / w0, wmt = wt / w0, wv = wee / w0 - wme * wme, wc = wet / w0 - wme * wmt;
-            if (wv > kEpsSmall) {
-                const double an = wc / wv, bn = wmt - an * wme;
-                const bool done = std::fabs(an - a) + std::fabs(bn - b) < 1e-6;
-                a = an; b = bn;
-                if (done) break;
-            }
-        }
-        double ssr = 0, sst = 0;
-        for (size_t i = 0; i < np; ++i) {
-            const double res = truths[i] - (a * fe[i] + b);
-            ssr += res * res;
-            sst += (truths[i] - mt) * (truths[i] - mt);
-        }
-        const float r2 = sst > kEpsSmall ? static_cast<float>(1.0 - ssr / sst) : 0.0f;
-        const double sxx = ve * static_cast<double>(np);
-        float max_lev = 0.0f;
-        if (sxx > kEpsSmall)
-            for (size_t i = 0; i < np; ++i)
-                max_lev = std::max(max_lev, static_cast<float>(1.0 / np + (fe[i] - me) * (fe[i] - me) / sxx));
-        if (r2 < 0.1f || max_lev > 4.0f / static_cast<float>(std::max(np, size_t(1)))) { a = 1.0; b = 0.0; }
-        cal.affine_a = static_cast<float>(a);
-        cal.affine_b = static_cast<float>(b);
-        std::sort(nn_d.begin(), nn_d.end());
-        cal.median_nn_dist_sq = nn_d[nn_d.size() / 2];
-        cal.min_slack_sq = std::max(kEpsSmall, cal.median_nn_dist_sq * 1e-4f);
-        std::vector<float> resid;
-        resid.reserve(cs.size());
-        for (const auto& s : cs) {
-            const float fq = std::max(s.ipq, cal.ip_qo_floor);
-            float ie = fq > kEpsMedium ? s.ipc / fq : 0.0f;
-            ie = cal.affine_a * ie + cal.affine_b;
-            const float ed = std::max(s.nop * s.nop + s.dqp - 2.0f * s.nop * ie, 0.0f);
-            resid.push_back(std::fabs(ed - l2sq(D, qbuf[s.qi].data(), hi.vec(s.nbr))));
-        }
-        std::sort(resid.begin(), resid.end());
-        const size_t nr = resid.size();
-        // the reference's min tail (sqrt(n)) is unreachable for n > ~230k; cap it (see header)
-        size_t min_tail = prof.evt_min_tail;
-        const size_t supply = static_cast<size_t>(std::sqrt(static_cast<double>(std::max(nr, size_t(4)))));
-        if (min_tail > supply / 2) min_tail = std::max<size_t>(64, supply / 2);
-        const float tmin = std::max(1.0f - 1.0f / std::sqrt(static_cast<float>(std::max(nr, size_t(4)))), 0.5f);
-        const float tmax = 1.0f - static_cast<float>(min_tail) / static_cast<float>(std::max(nr, size_t(1)));
-        cal.evt = fit_gpd_stable(resid.data(), nr, min_tail, tmin, tmax);
-        std::sort(nops.begin(), nops.end());
-        cal.median_nop = nops[nops.size() / 2];
-        if (!cal.evt.fitted || cal.median_nop <= 0.0f)
-            throw std::runtime_error("Calibration failed: EVT-CRC fit did not converge.");
-        const float ref = std::sqrt(std::max(cal.median_nn_dist_sq, cal.min_slack_sq));
-        const float q1 = resid[nr / 4] / ref, med = resid[nr / 2] / ref, q3 = resid[3 * nr / 4] / ref, iqr = q3 - q1;
-        cal.gamma_min = std::max(1.0f + resid[std::max(size_t(1), nr / 100)] / ref, 1.0f + 1.0f / std::sqrt(static_cast<float>(D)));
-        cal.gamma_max = std::max(1.0f + q3 + 1.5f * iqr, cal.gamma_min + std::max(iqr, med));
-        double rm = 0; for (float r : resid) rm += r; rm /= nr;
-        double rv = 0; for (float r : resid) rv += (r - rm) * (r - rm); rv /= nr;
-        const float cv = static_cast<float>(std::sqrt(rv) / std::max(rm, (double)kEpsSmall));
-        cal.gamma_beta = 1.0f / std::max(cv, 1.0f / std::sqrt(2.0f * static_cast<float>(std::max(nr, size_t(2)) - 1)));
-        cal.gamma_warmup = std::max(size_t(4), static_cast<size_t>(std::ceil(std::sqrt(static_cast<float>(cal.evt.n_tail)))));
-        cal.slack_levels = prof.slack_levels;
-        const int L = std::clamp(cal.slack_levels, 1, 32);
-        cal.search_num_slack_levels = L;
-        const float basel = 6.0f / (3.14159265358979f * 3.14159265358979f);
-        for (int i = 1; i <= L; ++i)
-            cal.search_ip_slack_levels[i - 1] =
-                evt_quantile(0.5e-4f * basel / (static_cast<float>(i) * static_cast<float>(i)), cal.evt) / (2.0f * cal.median_nop);
-        cal.search_gamma = std::clamp(1.0f + evt_quantile(0.5e-4f, cal.evt) / ref, cal.gamma_min, cal.gamma_max);
+        EncodeArgsB a{};
+        a.x = dev.raw.p; a.nbr = d_nbr_new.p; a.centroid = d_centroid.p; a.n = n; a.dim = (uint32_t)dim; a.D = (uint32_t)D;
+        a.epb = encode_edges_epb((uint32_t)D);
+        a.signs = d_signs.p; a.norm_factor = norm_factor; a.inv_sqrt_d = inv_sqrt_d; a.L = L; a.blocks = dev.blocks.p;
+        a.own = d_own.p; a.own_stride = own_stride; a.own_meta = own_meta;
+        const size_t lds = encode_edges_lds(a.D, a.epb);
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
+        launch_encode_bits(bw, a, (uint32_t)std::min<uint64_t>(n, (uint64_t)num_cus * per_cu), lds);
+        a.nbr = nullptr;
+        launch_encode_bits(bw, a, (uint32_t)std::min<uint64_t>((n + 31) / 32, (uint64_t)num_cus * per_cu), lds);
+        HIP_CHECK(hipDeviceSynchronize());
     }
-    std::memcpy(hi.calib, &cal, 248);
+    tm.lap("gather + edge / own codes");
+
+    // ---- upper layers: concurrent incremental insertion on the host (5 % of the vertices) ----------------------
+    std::vector<int32_t> levels_new(n);
+    for (size_t nw = 0; nw < n; ++nw) levels_new[nw] = levels[new_to_old[nw]];
+    UpperLayers ul(vecs, dim, n, levels, max_level, entry_old, M_UPPER, R);
+    ul.build();
+    std::vector<std::vector<UpperEdge>> upper = ul.export_layers(old_to_new);
+    const float upper_tau = ul.tau, upper_alpha = ul.alpha;
+    tm.lap("upper layers (host, concurrent)");
+
+    // ---- host image: the reference's file layout derived from the device arrays ------------------------------
+    hi.raw.resize(n * D);
+    hi.norm_sq.resize(n);
+    HIP_CHECK(hipMemcpy(hi.raw.data(), dev.raw.p, n * D * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hi.norm_sq.data(), dev.norm.p, n * 4, hipMemcpyDeviceToHost));
+    hi.levels = std::move(levels_new);
+    hi.search_data.assign(n * hi.RL.vertex_bytes, 0);
+    {
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (512u << 20) / L.stride));
+        std::vector<uint8_t> stage(chunk * L.stride), own(chunk * own_stride);
+        for (size_t base = 0; base < n; base += chunk) {
+            const size_t c = std::min(chunk, n - base);
+            HIP_CHECK(hipMemcpy(stage.data(), dev.blocks.p + base * L.stride, c * L.stride, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(own.data(), d_own.p + base * own_stride, c * own_stride, hipMemcpyDeviceToHost));
+            parallel_for(c, 256, [&](size_t lo, size_t hi_) {
+                for (size_t v = lo; v < hi_; ++v) {
+                    uint8_t* dst = &hi.search_data[(base + v) * hi.RL.vertex_bytes];
+                    std::memcpy(dst, &own[v * own_stride], own_stride);
+                    repack_dev_to_ref(&stage[v * L.stride], L, hi.RL, dst + hi.RL.nb_off);
+                }
+            });
+        }
+    }
+    hi.upper = std::move(upper);
+    hi.max_level = max_level;
+    hi.entry = old_to_new[entry_old];
+    hi.upper_tau = upper_tau;
+    hi.upper_alpha = upper_alpha;
+    hi.centroid = centroid;
+    ProfileRecord prof;
+    prof.n = n; prof.D = D; prof.R = R; prof.bits = bw;
+    prof.evt_min_tail = std::max<size_t>(64, isqrt_sz(n));                                       // adaptive_defaults.hpp:45-46
+    prof.min_calib_samples = std::clamp((size_t)(10.0 * std::sqrt((double)n)), (size_t)200, n);   // :48-52
+    prof.slack_levels = std::clamp((int)std::ceil(std::log2(std::max(10.0f * std::log2((float)std::max(n, (size_t)64)), 4.0f))), 4, 32);
+    prof.graph_stats = gs;
     std::memcpy(hi.profile, &prof, 72);
-    note("calibration");
-    hi.validate();
+    std::memset(hi.calib, 0, sizeof(hi.calib));
+    tm.lap("host image");
+}
+
+// What the calibration needs from the device-resident index.
+struct DeviceIndexView {
+    const uint8_t* blocks;
+    const float* raw;
+    const float* signs;
+    DevLayout L;
+    float norm_factor, inv_sqrt_d;
+};
+
+// Estimator calibration: samples evaluated on the GPU, statistics on the host; writes hi.calib.
+inline void calibrate(HostIndex& hi, const DeviceIndexView& dv, int num_cus, bool verbose) {
+    StageTimer tm{verbose};
+    const size_t n = hi.n, D = hi.D, dim = hi.dim, bw = hi.bw;
+    if (n < 50) throw std::runtime_error("Calibration requires at least 50 nodes.");
+    ProfileRecord prof;
+    std::memcpy(&prof, hi.profile, 72);
+    // ---- sample queries: database vectors (start = themselves) and perturbed ones (start = elsewhere) ----
+    const size_t n_db = std::min(prof.min_calib_samples, n), n_syn = std::min(prof.min_calib_samples / 2, n);
+    const size_t ns = n_db + n_syn;
+    std::mt19937 rng(42 + 99999);
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::shuffle(order.begin(), order.end(), rng);
+    std::vector<float> sigma(dim, 0.0f);
+    {
+        const size_t vs = std::max<size_t>(2, std::min(n, prof.min_calib_samples / 4));
+        std::vector<double> s1(dim, 0.0), s2(dim, 0.0);
+        for (size_t i = 0; i < vs; ++i) {
+            const float* v = hi.vec(order[i]);
+            for (size_t d = 0; d < dim; ++d) { s1[d] += v[d]; s2[d] += (double)v[d] * v[d]; }
+        }
+        for (size_t d = 0; d < dim; ++d) {
+            const double mu = s1[d] / vs;
+            sigma[d] = (float)std::sqrt(std::max(s2[d] / vs - mu * mu, (double)kEpsSmall));
+        }
+    }
+    std::vector<float> q(ns * dim);
+    std::vector<uint32_t> start(ns);
+    for (size_t i = 0; i < n_db; ++i) {
+        std::memcpy(&q[i * dim], hi.vec(order[i]), dim * 4);
+        start[i] = order[i];
+    }
+    std::normal_distribution<float> gauss(0.0f, 1.0f);
+    for (size_t i = 0; i < n_syn; ++i) {
+        const float* base = hi.vec(order[i % n]);
+        for (size_t d = 0; d < dim; ++d) q[(n_db + i) * dim + d] = base[d] + gauss(rng) * sigma[d];
+        start[n_db + i] = order[(n_db + i) % n];
+    }
+    // ---- on the GPU: encode, hop, estimate vs exact ---------------------------------------------------------
+    const uint32_t PW = dv.L.PW;
+    DevBuf<float> d_q(ns * dim), d_qp(ns * D), d_rec(ns * 32 * 6), d_dqp(ns), d_ed(ns);
+    DevBuf<uint4> d_masks(ns * PW);
+    DevBuf<QueryHeader> d_hdr(ns);
+    DevBuf<uint32_t> d_start(ns), d_rc(ns);
+    HIP_CHECK(hipMemcpy(d_q.p, q.data(), ns * dim * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_start.p, start.data(), ns * 4, hipMemcpyHostToDevice));
+    {
+        EncodeArgs e{};
+        e.queries_raw = d_q.p; e.nq = (uint32_t)ns; e.dim = (uint32_t)dim; e.D = (uint32_t)D; e.PW = PW;
+        e.signs = dv.signs; e.norm_factor = dv.norm_factor; e.inv_sqrt_d = dv.inv_sqrt_d;
+        e.raw = dv.raw; e.n = n; e.entry = 0; e.max_level = 0;
+        e.queries_padded = d_qp.p; e.qmasks = d_masks.p; e.qhdr = d_hdr.p; e.entry_dist = d_ed.p;
+        hipLaunchKernelGGL(encode_kernel, dim3((uint32_t)std::min<uint64_t>(ns, (uint64_t)num_cus * 32)), dim3(64),
+                           encode_lds_bytes((uint32_t)D), nullptr, e);
+        HIP_CHECK(hipGetLastError());
+        CalibArgs c{};
+        c.blocks = dv.blocks; c.raw = dv.raw; c.L = dv.L; c.n = n; c.queries = d_qp.p; c.qmasks = d_masks.p; c.qhdr = d_hdr.p;
+        c.start = d_start.p; c.ns = (uint32_t)ns; c.rec = d_rec.p; c.rec_cnt = d_rc.p; c.dqp_out = d_dqp.p;
+        const size_t lds = (size_t)PW * 16 + (size_t)D * 8;
+        const dim3 grid((uint32_t)std::min<uint64_t>(ns, (uint64_t)num_cus * 16));
+        if (bw == 1) hipLaunchKernelGGL(calib_kernel<1>, grid, dim3(64), lds, nullptr, c);
+        else if (bw == 2) hipLaunchKernelGGL(calib_kernel<2>, grid, dim3(64), lds, nullptr, c);
+        else hipLaunchKernelGGL(calib_kernel<4>, grid, dim3(64), lds, nullptr, c);
+        HIP_CHECK(hipGetLastError());
+    }
+    std::vector<float> rec(ns * 32 * 6), dqp(ns);
+    std::vector<uint32_t> rc(ns);
+    HIP_CHECK(hipMemcpy(rec.data(), d_rec.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dqp.data(), d_dqp.p, ns * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(rc.data(), d_rc.p, ns * 4, hipMemcpyDeviceToHost));
+    tm.lap("calibration samples (GPU)");
+
+    // ---- statistics ---------------------------------------------------------------------------------------
+    CalibrationRecord cal{};
+    std::vector<float> ipqo, est_ratio, truth, nops;
+    struct Pair { float nop, ipc, ipq, dqp, exact; };
+    std::vector<Pair> pairs;
+    for (size_t s = 0; s < ns; ++s)
+        for (uint32_t j = 0; j < rc[s] && j < 32; ++j) {
+            const float* r = &rec[(s * 32 + j) * 6];
+            ipqo.push_back(r[5]);
+            nops.push_back(r[0]);
+            truth.push_back(r[3]);
+            pairs.push_back({r[0], r[1], r[2], dqp[s], r[4]});
+        }
+    if (ipqo.empty()) throw std::runtime_error("Calibration failed: no ip_qo samples.");
+    if (pairs.size() < 20) throw std::runtime_error("Calibration failed: too few estimator/target pairs.");
+    {   // floor of the estimator's denominator: a low robust quantile of the observed ip_qo
+        const float med = median_of(ipqo);
+        cal.ip_qo_floor = std::max(med - 3.0f * mad_sigma(ipqo, med), kEpsMedium);
+    }
+    est_ratio.resize(pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) est_ratio[i] = pairs[i].ipc / std::max(pairs[i].ipq, cal.ip_qo_floor);
+    {   // affine correction truth ~ a * estimate + b, kept only if it explains the data and no point dominates it
+        double a, b;
+        robust_line(est_ratio, truth, a, b);
+        const size_t np = truth.size();
+        double mt = 0, me = 0;
+        for (size_t i = 0; i < np; ++i) { mt += truth[i]; me += est_ratio[i]; }
+        mt /= np; me /= np;
+        double ssr = 0, sst = 0, sxx = 0;
+        for (size_t i = 0; i < np; ++i) {
+            const double res = truth[i] - (a * est_ratio[i] + b);
+            ssr += res * res;
+            sst += (truth[i] - mt) * (truth[i] - mt);
+            sxx += (est_ratio[i] - me) * (est_ratio[i] - me);
+        }
+        const double r2 = sst > kEpsSmall ? 1.0 - ssr / sst : 0.0;
+        double lev = 0.0;
+        if (sxx > kEpsSmall)
+            for (size_t i = 0; i < np; ++i) lev = std::max(lev, 1.0 / np + (est_ratio[i] - me) * (est_ratio[i] - me) / sxx);
+        if (r2 < 0.1 || lev > 4.0 / (double)np) { a = 1.0; b = 0.0; }
+        cal.affine_a = (float)a;
+        cal.affine_b = (float)b;
+    }
+    cal.median_nn_dist_sq = median_of(dqp);
+    cal.min_slack_sq = std::max(kEpsSmall, cal.median_nn_dist_sq * 1e-4f);
+    cal.median_nop = median_of(nops);
+    // residuals of the calibrated distance estimate
+    std::vector<float> resid(pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        const Pair& p = pairs[i];
+        const float den = std::max(p.ipq, cal.ip_qo_floor);
+        const float ip = cal.affine_a * (den > kEpsMedium ? p.ipc / den : 0.0f) + cal.affine_b;
+        const float est = std::max(p.nop * p.nop + p.dqp - 2.0f * p.nop * ip, 0.0f);
+        resid[i] = std::fabs(est - p.exact);
+    }
+    std::sort(resid.begin(), resid.end());
+    const size_t nr = resid.size();
+    // (F9) the reference's minimum tail is unreachable for large n: cap it at half of what the sample supplies
+    size_t min_tail = prof.evt_min_tail;
+    const size_t supply = isqrt_sz(std::max(nr, (size_t)4));
+    if (min_tail > supply / 2) min_tail = std::max<size_t>(64, supply / 2);
+    const float q_lo = std::max(1.0f - 1.0f / std::sqrt((float)std::max(nr, (size_t)4)), 0.5f);
+    const float q_hi = 1.0f - (float)min_tail / (float)std::max(nr, (size_t)1);
+    cal.evt = fit_tail(resid, min_tail, q_lo, q_hi);
+    if (!cal.evt.fitted || cal.median_nop <= 0.0f) throw std::runtime_error("Calibration failed: EVT-CRC fit did not converge.");
+    const float ref = std::sqrt(std::max(cal.median_nn_dist_sq, cal.min_slack_sq));
+    {
+        const float q1 = resid[nr / 4] / ref, med = resid[nr / 2] / ref, q3 = resid[3 * nr / 4] / ref, iqr = q3 - q1;
+        cal.gamma_min = std::max(1.0f + resid[std::max<size_t>(1, nr / 100)] / ref, 1.0f + 1.0f / std::sqrt((float)D));
+        cal.gamma_max = std::max(1.0f + q3 + 1.5f * iqr, cal.gamma_min + std::max(iqr, med));
+        double mu = 0, var = 0;
+        for (float r : resid) mu += r;
+        mu /= nr;
+        for (float r : resid) var += (r - mu) * (r - mu);
+        var /= nr;
+        const float cv = (float)(std::sqrt(var) / std::max(mu, (double)kEpsSmall));
+        cal.gamma_beta = 1.0f / std::max(cv, 1.0f / std::sqrt(2.0f * (float)(std::max(nr, (size_t)2) - 1)));
+        cal.gamma_warmup = std::max<size_t>(4, (size_t)std::ceil(std::sqrt((float)cal.evt.n_tail)));
+    }
+    cal.slack_levels = prof.slack_levels;
+    const int levels = std::clamp(cal.slack_levels, 1, 32);
+    cal.search_num_slack_levels = levels;
+    const float basel = 6.0f / (3.14159265358979f * 3.14159265358979f);    // sum 1/i^2 budget split
+    for (int i = 1; i <= levels; ++i)
+        cal.search_ip_slack_levels[i - 1] = tail_quantile(0.5e-4f * basel / ((float)i * (float)i), cal.evt) / (2.0f * cal.median_nop);
+    cal.search_gamma = std::clamp(1.0f + tail_quantile(0.5e-4f, cal.evt) / ref, cal.gamma_min, cal.gamma_max);
+    std::memcpy(hi.calib, &cal, 248);
+    tm.lap("calibration statistics");
 }
 
 }  // namespace build

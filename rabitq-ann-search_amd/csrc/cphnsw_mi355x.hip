@@ -18,6 +18,7 @@
 
 #include "../../include/cphnsw_mi355x.h"
 #include "cph_core.h"
+#include "device_buf.h"
 #include "device_encode.h"
 #include "device_fastscan.h"
 #include "device_search.h"
@@ -36,22 +37,9 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-struct HipError : std::runtime_error {
-    using std::runtime_error::runtime_error;
-};
 struct InvalidArg : std::invalid_argument {
     using std::invalid_argument::invalid_argument;
 };
-
-#define HIP_CHECK(expr)                                                                   \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess) {                                                           \
-            if (e_ == hipErrorOutOfMemory) throw std::bad_alloc();                        \
-            throw HipError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + \
-                           #expr);                                                        \
-        }                                                                                 \
-    } while (0)
 
 template <class F>
 int guarded(F&& f) {
@@ -72,24 +60,6 @@ size_t next_pow2(size_t n) {
     while (p < n) p *= 2;
     return p;
 }
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    void alloc(size_t count) {
-        if (count <= n && p) return;
-        release();
-        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T)));
-        n = count;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    ~DevBuf() { release(); }
-};
 
 void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
     // at most 64 host threads per process: eight ranks share one node (one process per GPU)
@@ -214,13 +184,13 @@ void quiesce(cph_index* h) {
         if (s.used && s.ev_done) HIP_CHECK(hipEventSynchronize(s.ev_done));
 }
 
-void upload_index(cph_index* h) {
+// The big arrays of a loaded index: blocks repacked into the device layout, vectors, norms.  (An index
+// built here already has them in HBM: build::build_graph.)
+void upload_arrays(cph_index* h) {
     h->use_device();
     quiesce(h);
     const HostIndex& hi = h->host;
     h->L = make_dev_layout((uint32_t)hi.D, (uint32_t)hi.bw);
-    h->sc = hi.consts();
-    h->flags = hi.has_dup_neighbors ? 1u : 0u;
     const size_t n = hi.n;
     const size_t stride = h->L.stride;
     h->d_blocks.alloc(n * stride + 64);
@@ -240,6 +210,17 @@ void upload_index(cph_index* h) {
     }
     HIP_CHECK(hipMemcpy(h->d_raw.p, hi.raw.data(), n * hi.D * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(h->d_norm.p, hi.norm_sq.data(), n * 4, hipMemcpyHostToDevice));
+}
+
+// Everything else the query path needs on the device: search constants, rotation signs, upper layers.
+void upload_feeders(cph_index* h) {
+    h->use_device();
+    quiesce(h);
+    const HostIndex& hi = h->host;
+    const size_t n = hi.n;
+    h->L = make_dev_layout((uint32_t)hi.D, (uint32_t)hi.bw);
+    h->sc = hi.consts();
+    h->flags = hi.has_dup_neighbors ? 1u : 0u;
     // rotation signs and the scale factors of the query encoder (rabitq_encoder.hpp:37-39)
     h->d_signs.alloc(3 * hi.D);
     HIP_CHECK(hipMemcpy(h->d_signs.p, hi.rot.signs.data(), 3 * hi.D * 4, hipMemcpyHostToDevice));
@@ -576,7 +557,8 @@ int cph_load(cph_index* h, const char* path) {
         if (!h || !path) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
         h->host.load(path, h->D, h->bits, h->dim);  // commits only on success
-        upload_index(h);
+        upload_arrays(h);
+        upload_feeders(h);
         h->finalized = true;
     });
 }
@@ -631,11 +613,22 @@ int cph_finalize(cph_index* h) {
         if (n >= 0xFFFFFFFFull) throw InvalidArg("too many vectors");
         h->use_device();
         const bool verbose = getenv("CPH_BUILD_VERBOSE") != nullptr;
-        build::finalize_index(h->host, h->pending.data(), n, h->dim, h->D, h->bits, h->num_cus, verbose);
+        quiesce(h);
+        h->d_blocks.release(); h->d_raw.release(); h->d_norm.release();
+        for (auto& s : h->sets) release_scratch(s);
+        build::BuiltDevice dev;
+        build::build_graph(h->host, dev, h->pending.data(), n, h->dim, h->D, h->bits, h->num_cus, verbose);
         std::vector<float>().swap(h->pending);
         h->pending_n = 0;
         h->needs_build = false;
-        upload_index(h);
+        // the pipeline's device arrays are the searchable index: adopt them, no second upload
+        h->d_blocks = std::move(dev.blocks);
+        h->d_raw = std::move(dev.raw);
+        h->d_norm = std::move(dev.norm);
+        upload_feeders(h);
+        build::DeviceIndexView view{h->d_blocks.p, h->d_raw.p, h->d_signs.p, h->L, h->norm_factor, h->inv_sqrt_d};
+        build::calibrate(h->host, view, h->num_cus, verbose);
+        h->sc = h->host.consts();
         h->finalized = true;
     });
 }
@@ -667,6 +660,48 @@ int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t di
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
         build::gpu_knn(queries ? q.data() : nullptr, queries ? qn.data() : nullptr, nq, x.data(), nrm.data(), n, D,
                        cus, ids, dist);
+    });
+}
+
+int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* parent, const float* nbrs, uint64_t cnt,
+                     uint8_t* values, float* aux, uint32_t* pops) {
+    return guarded([&] {
+        if (!parent || !nbrs || !values || !aux || !pops || cnt == 0 || cnt > 32 || dim == 0) throw InvalidArg("bad arguments");
+        if (bits != 1 && bits != 2 && bits != 4) throw InvalidArg("bits must be 1, 2 or 4");
+        const size_t D = std::max<size_t>(16, next_pow2(dim));
+        if (D > 2048) throw InvalidArg("unsupported dimension");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t n = cnt + 1;                       // vertex 0 = the parent, 1..cnt = its neighbours
+        std::vector<float> x(n * D, 0.0f);
+        std::memcpy(x.data(), parent, dim * 4);
+        for (uint64_t e = 0; e < cnt; ++e) std::memcpy(&x[(e + 1) * D], nbrs + e * dim, dim * 4);
+        std::vector<uint32_t> nbr(n * 32, kInvalidNode);
+        for (uint64_t e = 0; e < cnt; ++e) nbr[e] = (uint32_t)(e + 1);
+        Rotation rot;
+        rot.init(D, 42);
+        const DevLayout L = make_dev_layout((uint32_t)D, (uint32_t)bits);
+        DevBuf<float> d_x(n * D), d_signs(3 * D), d_aux(n * 32 * 3);
+        DevBuf<uint32_t> d_nbr(n * 32), d_pops(n * 32 * 2);
+        DevBuf<uint8_t> d_blocks(n * L.stride), d_vals(n * 32 * D);
+        HIP_CHECK(hipMemcpy(d_x.p, x.data(), n * D * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_nbr.p, nbr.data(), n * 32 * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_signs.p, rot.signs.data(), 3 * D * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(d_blocks.p, 0, n * L.stride));
+        HIP_CHECK(hipMemset(d_vals.p, 0, n * 32 * D));
+        HIP_CHECK(hipMemset(d_aux.p, 0, n * 32 * 3 * 4));
+        HIP_CHECK(hipMemset(d_pops.p, 0, n * 32 * 2 * 4));
+        build::EncodeArgsB a{};
+        const float df = (float)D;
+        a.x = d_x.p; a.nbr = d_nbr.p; a.n = n; a.dim = (uint32_t)dim; a.D = (uint32_t)D;
+        a.epb = build::encode_edges_epb((uint32_t)D);
+        a.signs = d_signs.p; a.norm_factor = 1.0f / (df * std::sqrt(df)); a.inv_sqrt_d = 1.0f / std::sqrt(df);
+        a.L = L; a.blocks = d_blocks.p;
+        a.dbg_values = d_vals.p; a.dbg_aux = d_aux.p; a.dbg_pops = d_pops.p;
+        build::launch_encode_bits(bits, a, 1, build::encode_edges_lds(a.D, a.epb));
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(values, d_vals.p, cnt * D, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(aux, d_aux.p, cnt * 3 * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(pops, d_pops.p, cnt * 2 * 4, hipMemcpyDeviceToHost));
     });
 }
 

@@ -131,8 +131,9 @@ struct HostIndex {
     std::vector<float> centroid;
     std::vector<int32_t> levels;
     std::vector<float> norm_sq;
-    std::vector<float> raw;           // [n][D]
-    std::vector<uint8_t> search_data; // n * vertex_bytes, reference layout (kept for save)
+    std::vector<float> raw;           // [n][D]  (empty when the vectors are served from a mapped native file)
+    const float* raw_view = nullptr;  // [n][D] inside a mapped native file (csrc/native_file.h), else null
+    std::vector<uint8_t> search_data; // n * vertex_bytes, reference layout (kept for save; a native load rebuilds it on demand)
     std::vector<std::vector<UpperEdge>> upper;
     RefLayout RL;
     Rotation rot;
@@ -269,7 +270,7 @@ struct HostIndex {
         wr(centroid.data(), dim * 4);
         wr(levels.data(), n * 4);
         wr(norm_sq.data(), n * 4);
-        wr(raw.data(), n * D * 4);
+        wr(vec(0), n * D * 4);
         wr(search_data.data(), search_data.size());
         const uint32_t nl = (uint32_t)upper.size();
         wr(&nl, 4);
@@ -285,7 +286,7 @@ struct HostIndex {
     }
 
     const uint8_t* nb(size_t v) const { return &search_data[v * RL.vertex_bytes + RL.nb_off]; }
-    const float* vec(size_t v) const { return &raw[v * D]; }
+    const float* vec(size_t v) const { return (raw_view ? raw_view : raw.data()) + v * D; }
 };
 
 // ---- reference neighbour block <-> device block -----------------------------------------

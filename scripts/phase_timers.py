@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--no-timers", action="store_true")
     ap.add_argument("--lib", default=LIB, help="library to build / load")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--index", default="/tmp/cph_bench/bench_n1000000_b4.idx")
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--index", default="", help="index file (default: the bench cache of --config)")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--product", action="store_true", help="run the shipped library (no timers), e.g. under rocprofv3 --pmc")
@@ -42,10 +43,17 @@ def main():
     import torch
     import bench
     from cphnsw_mi355x import CPIndex
+    cfg = bench.CONFIGS[args.config]
+
+    class _A:
+        workdir = os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench")
+        config = args.config
+    if not args.index:
+        args.index = bench.index_path(_A, cfg, cfg["n"])
     if not os.path.exists(args.index):
-        raise SystemExit(f"{args.index} missing: run bench.py once to build it")
-    _, Q = bench.make_data(1000000, args.nq, need_base=False)
-    idx = CPIndex(dim=128, bits=4)
+        raise SystemExit(f"{args.index} missing: run bench.py --config {args.config} once to build it")
+    Q = bench.make_queries(cfg, cfg["n"], args.nq)
+    idx = CPIndex(dim=cfg["dim"], bits=cfg["bits"])
     idx.load(args.index)
     q = torch.from_numpy(Q).cuda()
     best = 1e9
@@ -53,7 +61,9 @@ def main():
         idx.search_batch_device(q, args.k)
         torch.cuda.synchronize()
         best = min(best, idx.last_search_stats()["kernel_us"])
-    print("product" if args.product else os.path.basename(args.lib), "nq", args.nq, "best kernel_us", best, idx.last_search_stats())
+    import json
+    print(json.dumps({"lib": "product" if args.product else os.path.basename(args.lib), "config": args.config, "nq": args.nq, "k": args.k,
+                      "best_kernel_us": best, "stats": idx.last_search_stats()}))
 
 
 if __name__ == "__main__":

@@ -75,3 +75,52 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _gpu_worker(port, q):
+    """One rank over RCCL: the HIP search_batch as the shard's search function, device tensors gathered."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+    import torch
+    import torch.distributed as dist
+    from golden_util import fixture_path, golden
+    import cphnsw_mi355x
+    from cphnsw_mi355x.dist import gather_results, search_batch_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ix = cphnsw_mi355x.CPIndex(128, 4, device=0)
+        ix.load(fixture_path("g128", 4))
+        Q = golden()["Q/g128"]
+        ids, d = search_batch_sharded(ix.search_batch, Q, 10, device=dev)      # numpy in/out through the all-gather
+        # the device-resident path of bench.py: search_batch_device on a side stream + all_gather_into_tensor
+        st = torch.cuda.Stream(dev)
+        qd = torch.from_numpy(Q).to(dev)
+        torch.cuda.synchronize()
+        di, dd = ix.search_batch_device(qd, 10, stream=st)
+        with torch.cuda.stream(st):
+            gi, gd = gather_results(di, dd, 1, force=True)
+        st.synchronize()
+        q.put((ids, d, gi.cpu().numpy(), gd.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_gather_of_hip_search_matches_goldens(gold):
+    """search_batch_sharded / gather_results with the HIP search over RCCL (nccl backend, world_size 1 on the
+    one-GPU box): the collective path bench.py times for N > 1, against the reference's goldens."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_gpu_worker, args=(_free_port(), q))
+    p.start()
+    ids, d, gi, gd = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for a, b in ((ids, d), (gi, gd)):
+        assert np.array_equal(a, gold["S/g128/b4/plain/k10/ids"])
+        assert b.tobytes() == gold["S/g128/b4/plain/k10/d"].tobytes()

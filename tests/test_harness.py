@@ -51,3 +51,54 @@ def test_run_benchmark_end_to_end(tmp_path):
     assert r["recall_at_100"] > 0.2
     saved = json.loads((tmp_path / "res" / "sift1m_results.json").read_text())
     assert saved["metadata"]["n_base"] == n and saved["metadata"]["k"] == 100
+
+
+def _harness_fixture():
+    import os
+    from golden_util import GOLDEN_DIR
+    z = np.load(os.path.join(GOLDEN_DIR, "harness.npz"))
+    return z, json.loads(bytes(z["metrics_json"]).decode()), json.loads(bytes(z["reference_run_json"]).decode())
+
+
+def test_scores_match_the_reference_harness():
+    """cphnsw_mi355x.eval.score_as_reference on the ids the reference returned for the fixture index against
+    what the reference's own recall_at_k / ADR code computed for them (tests/golden/make_golden_harness.py)."""
+    from cphnsw_mi355x.eval import score_as_reference
+    z, metrics, ref_run = _harness_fixture()
+    got = score_as_reference(z["ids"], z["base"], z["queries"], z["groundtruth"], int(z["k"]))
+    assert got == metrics
+    # schema of a real reference run: every key it writes exists in ours (tested on the GPU below)
+    assert set(ref_run["metadata"]) == {"timestamp", "dataset", "n_base", "n_queries", "dim", "metric", "k", "n_runs"}
+
+
+@pytest.mark.gpu
+def test_harness_on_reference_built_index_reproduces_reference_numbers(tmp_path):
+    """The fixture index was built and searched by the reference; the GPU drop-in loaded from the same file
+    must return the same ids and distances, hence the reference harness' numbers to the last digit; and a
+    full run_benchmark writes a superset of the keys a real reference run wrote."""
+    import gzip
+    import os
+    import cphnsw_mi355x
+    from cphnsw_mi355x.datasets import write_vecs
+    from cphnsw_mi355x.eval import run_benchmark, score_as_reference
+    from golden_util import GOLDEN_DIR
+    z, metrics, ref_run = _harness_fixture()
+    p = tmp_path / "h.idx"
+    p.write_bytes(gzip.open(os.path.join(GOLDEN_DIR, "idx_harness_b4.idx.gz"), "rb").read())
+    ix = cphnsw_mi355x.CPIndex(128, 4)
+    ix.load(str(p))
+    ids, d = ix.search_batch(z["queries"], int(z["k"]))
+    assert np.array_equal(ids, z["ids"]) and d.tobytes() == z["dist"].tobytes()
+    assert score_as_reference(ids, z["base"], z["queries"], z["groundtruth"], int(z["k"])) == metrics
+    root = tmp_path / "data" / "sift1m"
+    root.mkdir(parents=True)
+    write_vecs(root / "sift_base.fvecs", z["base"])
+    write_vecs(root / "sift_query.fvecs", z["queries"])
+    write_vecs(root / "sift_groundtruth.ivecs", z["groundtruth"])
+    out = run_benchmark("sift1m", tmp_path / "data", k=int(z["k"]), n_runs=2, output_dir=tmp_path / "res", bit_widths=(4,))
+    assert set(ref_run["metadata"]) <= set(out["metadata"])
+    assert set(ref_run["results"][0]) <= set(out["results"][0])
+    ours, theirs = out["results"][0], [r for r in ref_run["results"] if r["algorithm"].endswith("4bit")][0]
+    # same protocol on the same data: the uncorrected scores land where the reference's own run did
+    assert abs(ours["as_reference"]["recall_at_100"] - theirs["recall_at_100"]) < 0.1
+    assert 0.5 < ours["as_reference"]["adr"] / theirs["adr"] < 2.0
