@@ -61,6 +61,11 @@ int cph_destroy(cph_index* h);
 
 int cph_load(cph_index* h, const char* path);
 int cph_save(cph_index* h, const char* path);
+/* GPU-native index file (csrc/native_file.h): the device block layout, vectors and norms as the GPU reads
+ * them, so loading is an mmap plus two host-to-device copies instead of the v2 file's per-vertex
+ * re-layout.  A handle loaded this way can still write a v2 file (cph_save) for the reference. */
+int cph_save_native(cph_index* h, const char* path);
+int cph_load_native(cph_index* h, const char* path);
 int cph_size(cph_index* h, uint64_t* n);
 int cph_dim(cph_index* h, uint64_t* dim);
 int cph_is_finalized(cph_index* h, int* flag);

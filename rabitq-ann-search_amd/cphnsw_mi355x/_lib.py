@@ -14,6 +14,8 @@ SYMBOLS = {
     "cph_destroy": (C.c_int, [C.c_void_p]),
     "cph_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cph_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cph_save_native": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cph_load_native": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cph_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cph_dim": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cph_is_finalized": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

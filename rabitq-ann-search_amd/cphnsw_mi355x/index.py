@@ -109,6 +109,13 @@ class CPIndex:
     def load(self, path):
         _lib.check(_lib.lib().cph_load(self._h, str(path).encode()))
 
+    def save_native(self, path):
+        """GPU-native file (device block layout; not readable by the reference): fast to load."""
+        _lib.check(_lib.lib().cph_save_native(self._h, str(path).encode()))
+
+    def load_native(self, path):
+        _lib.check(_lib.lib().cph_load_native(self._h, str(path).encode()))
+
     # -- properties -------------------------------------------------------------------------
     @property
     def size(self):

@@ -14,7 +14,7 @@
 //      vertices at a time under per-vertex locks (reference: one vertex at a time, api/hnsw_index.hpp:505-716).
 //      Insertion order is what makes these layers navigable -- early vertices keep long links -- which a
 //      batch k-NN construction on the GPU does not reproduce (measured: recall of the graph-quality test
-//      0.68 with per-level exact k-NN + selection, 0.72 with insertion, reference 0.73)
+//      0.68 with per-level exact k-NN + selection, 0.72 with insertion, reference 0.71)
 //   6. calibration: sample evaluation on the GPU (calib_kernel), robust statistics, affine fit and
 //      extreme-value tail fit on the host                              (api/hnsw_index.hpp:718-1139, core/evt_crc.hpp)
 //

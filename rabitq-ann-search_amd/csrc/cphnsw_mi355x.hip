@@ -24,6 +24,7 @@
 #include "device_search.h"
 #include "device_stream.h"
 #include "host_index.h"
+#include "native_file.h"
 #include "builder_pipeline.h"
 
 using namespace cph;
@@ -150,6 +151,9 @@ struct cph_index {
     UpperLayerDev layers[kMaxUpperLayers];
     int32_t dev_max_level = 0;
     float norm_factor = 0.0f, inv_sqrt_d = 0.0f;
+    // an index loaded from a native file keeps the mapping: vectors and own-code headers are served from it
+    NativeMapping native_map;
+    const uint8_t* own_view = nullptr;
     BatchSet sets[2];
     int last_set = 1;                  // the set handed out last (the two alternate)
     int last_search = -1;              // the set the most recent search went to
@@ -277,6 +281,30 @@ void upload_feeders(cph_index* h) {
     for (auto& s : h->sets) release_scratch(s);
     h->auto_cap = 0;
     h->last_search = -1;
+}
+
+// The reference-layout image of an index that came from a native file: own-code headers from the mapping,
+// neighbour blocks re-derived from the device blocks.
+void materialize_search_data(cph_index* h) {
+    HostIndex& hi = h->host;
+    if (!hi.search_data.empty() || hi.n == 0) return;
+    h->use_device();
+    quiesce(h);
+    const size_t n = hi.n, stride = h->L.stride, own_stride = hi.RL.nb_off;
+    hi.search_data.assign(n * hi.RL.vertex_bytes, 0);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (512u << 20) / stride));
+    std::vector<uint8_t> stage(chunk * stride);
+    for (size_t base = 0; base < n; base += chunk) {
+        const size_t c = std::min(chunk, n - base);
+        HIP_CHECK(hipMemcpy(stage.data(), h->d_blocks.p + base * stride, c * stride, hipMemcpyDeviceToHost));
+        parallel_for(c, 256, [&](size_t lo, size_t hi_) {
+            for (size_t v = lo; v < hi_; ++v) {
+                uint8_t* dst = &hi.search_data[(base + v) * hi.RL.vertex_bytes];
+                if (h->own_view) std::memcpy(dst, h->own_view + (base + v) * own_stride, own_stride);
+                repack_dev_to_ref(&stage[v * stride], h->L, hi.RL, dst + hi.RL.nb_off);
+            }
+        });
+    }
 }
 
 // Picks the set for the next batch (the two alternate) and makes `st` wait for the batch that
@@ -557,6 +585,8 @@ int cph_load(cph_index* h, const char* path) {
         if (!h || !path) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
         h->host.load(path, h->D, h->bits, h->dim);  // commits only on success
+        h->native_map.reset();
+        h->own_view = nullptr;
         upload_arrays(h);
         upload_feeders(h);
         h->finalized = true;
@@ -568,7 +598,55 @@ int cph_save(cph_index* h, const char* path) {
         if (!h || !path) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
         if (!h->finalized) throw std::runtime_error("Index must be finalized before saving.");
+        materialize_search_data(h);
         h->host.save(path);
+    });
+}
+
+int cph_save_native(cph_index* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->finalized) throw std::runtime_error("Index must be finalized before saving.");
+        h->use_device();
+        quiesce(h);
+        const HostIndex& hi = h->host;
+        const size_t n = hi.n, stride = h->L.stride, own_stride = hi.RL.nb_off;
+        std::vector<uint8_t> blocks(n * stride), own;
+        HIP_CHECK(hipMemcpy(blocks.data(), h->d_blocks.p, n * stride, hipMemcpyDeviceToHost));
+        const uint8_t* own_p = h->own_view;
+        if (!own_p) {
+            own.resize(n * own_stride);
+            for (size_t v = 0; v < n; ++v) std::memcpy(&own[v * own_stride], &hi.search_data[v * hi.RL.vertex_bytes], own_stride);
+            own_p = own.data();
+        }
+        write_native(path, hi, (uint32_t)stride, own_p, (uint32_t)own_stride, blocks.data());
+    });
+}
+
+int cph_load_native(cph_index* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) throw InvalidArg("null argument");
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->use_device();
+        quiesce(h);
+        HostIndex t;
+        NativeMapping map;
+        const NativeHeader nh = read_native(path, h->D, h->bits, h->dim, t, map);   // commits only on success
+        h->host = std::move(t);
+        h->native_map = std::move(map);
+        const uint8_t* base = static_cast<const uint8_t*>(h->native_map.base);
+        h->own_view = base + nh.own_off;
+        h->L = make_dev_layout((uint32_t)h->host.D, (uint32_t)h->host.bw);
+        const size_t n = h->host.n;
+        h->d_blocks.alloc(n * nh.stride + 64);
+        h->d_raw.alloc(n * h->host.D);
+        h->d_norm.alloc(n);
+        HIP_CHECK(hipMemcpy(h->d_blocks.p, base + nh.blocks_off, n * (size_t)nh.stride, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(h->d_raw.p, h->host.raw_view, n * h->host.D * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(h->d_norm.p, h->host.norm_sq.data(), n * 4, hipMemcpyHostToDevice));
+        upload_feeders(h);
+        h->finalized = true;
     });
 }
 
@@ -592,6 +670,8 @@ int cph_build(cph_index* h, const float* vectors, uint64_t n) {
         h->use_device();
         quiesce(h);
         h->host = HostIndex();
+        h->native_map.reset();
+        h->own_view = nullptr;
         h->finalized = false;
         h->d_blocks.release(); h->d_raw.release(); h->d_norm.release();
         for (auto& s : h->sets) release_scratch(s);
