@@ -225,7 +225,24 @@ __device__ __forceinline__ void beam_pop_wave(const Beam& h, uint32_t size, int 
     // the path is a prefix of it -- p_t = (hp >> (d - t)) - 1.  The loop is scalar-only; each lane
     // then derives its own pair of path positions with two shifts.
     uint32_t hp = 1, d = 0;
-    if (nint <= 64) {                              // the usual case: one mask, three scalar ops less per level
+    if (nint <= 63) {
+        // The usual case, four scalar instructions per level: with the mask shifted up by one, node hp - 1's
+        // bit sits at position hp; s_bitcmp0 puts "the right child moves up" into SCC and s_addc turns
+        // hp into 2 hp + SCC.  The depth is recovered from hp's leading one afterwards.
+        if (nint >= 1) {
+            const unsigned long long ms = m0 << 1;
+            asm volatile(
+                "1:\n\t"
+                "s_bitcmp0_b64 %[m], %[hp]\n\t"
+                "s_addc_u32 %[hp], %[hp], %[hp]\n\t"
+                "s_cmp_le_u32 %[hp], %[n]\n\t"
+                "s_cbranch_scc1 1b"
+                : [hp] "+s"(hp)
+                : [m] "s"(ms), [n] "s"(nint)
+                : "scc");
+            d = 31u - (uint32_t)__builtin_clz(hp);
+        }
+    } else if (nint <= 64) {                       // one mask, but node 63's bit does not survive the shift
         while (hp - 1 < nint) {
             const uint32_t left = (uint32_t)(m0 >> (hp - 1)) & 1u;
             hp = 2 * hp + 1 - left;
