@@ -1,6 +1,8 @@
 """ctypes binding of libcphnsw_mi355x.so — exactly the symbols include/cphnsw_mi355x.h declares."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 from . import build as _build
 
@@ -56,6 +58,28 @@ SYMBOLS = {
 _LIB = None
 
 
+def _share_hip_runtime_with_torch():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64.  If this library pulled in the
+    system copies first and torch were imported afterwards, the process would hold two HSA runtimes and torch
+    would report "No HIP GPUs are available".  When torch is installed but not imported yet, load ITS HIP
+    runtime first (same soname: our library then binds to it, exactly as it does when torch was imported
+    first); torch itself is not imported."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads (building if needed) the HIP library.  There is no fallback: if the library cannot
     be built or loaded the product path is unavailable and this raises."""
@@ -66,6 +90,7 @@ def lib():
             path = _build.LIB_PATH
             if _build.needs_build():
                 path = _build.build_library()
+        _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -1196,6 +1196,14 @@ void stream_launch(cph_stream* s, float* out_est, float* out_lower, uint64_t fir
     a.count = count;
     static const int mult = getenv("CPH_STREAM_GRID_MULT") ? atoi(getenv("CPH_STREAM_GRID_MULT")) : 32;
     const uint32_t grid = (uint32_t)s->num_cus * mult;
+    static const bool pair = !(getenv("CPH_STREAM_PAIR") && atoi(getenv("CPH_STREAM_PAIR")) == 0);
+    if (pair && s->L.D == 128 && s->L.BW <= 2) {
+        // narrow codes: two blocks per wave iteration, one per lane half (device_stream.h)
+        if (s->L.BW == 1) hipLaunchKernelGGL((fastscan_stream_pair_kernel<1>), dim3(grid), dim3(256), 64, st, a);
+        else hipLaunchKernelGGL((fastscan_stream_pair_kernel<2>), dim3(grid), dim3(256), 64, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     CPH_LAUNCH(fastscan_stream_kernel, s->L.BW, s->L.D, dim3(grid), dim3(256), (size_t)s->L.PW * 16, st, a);
 }
 

@@ -80,6 +80,81 @@ __global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
     if (lane == 0 && !a.out_est) a.sink[wave] = acc;
 }
 
+// Narrow codes at D = 128 (1 and 2 bits: 512 B / 1 KiB of codes per block).  With one block per wave iteration
+// the kernel above is bound by the VECTOR ALU, not by HBM: the estimator epilogue runs on 64 lanes for 32
+// neighbours and costs as much as for 4-bit codes while the block is less than half as long (measured 0.50 /
+// 0.60 of peak).  Here every wave iteration takes TWO consecutive blocks, one per lane half: lane (h, i) loads
+// all of neighbour i's code chunks of block 2p + h (each load instruction still reads 2 x 512 contiguous bytes),
+// needs no cross-half exchange, and the epilogue's instructions serve 64 neighbours.
+template <int BW>
+__global__ __launch_bounds__(256) void fastscan_stream_pair_kernel(StreamArgs a) {
+    static_assert(BW == 1 || BW == 2, "pair kernel: narrow codes only");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4* qm = reinterpret_cast<uint4*>(smem);
+    for (uint32_t w = threadIdx.x; w < 4; w += blockDim.x) qm[w] = a.qmask[w];     // D = 128: four mask words
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, i = lane & 31;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const float sq = __builtin_sqrtf(a.dqp);
+    float acc = 0.0f;
+    const uint64_t lo = a.out_est ? a.first : 0;
+    const uint64_t hi = a.out_est ? a.first + a.count : a.n_blocks;
+    struct Loads { uint4 c[BW]; uint4 aux; uint32_t id; };
+    auto issue = [&](uint64_t b, Loads& L) {
+        const uint8_t* blk = a.blocks + b * a.L.stride;
+        const uint4* cp = reinterpret_cast<const uint4*>(blk) + i;
+#pragma unroll
+        for (int k = 0; k < BW; ++k) L.c[k] = cp[k * 32];          // plane k of neighbour i ([k][half][neighbour] order)
+        L.aux = reinterpret_cast<const uint4*>(blk + a.L.aux_off)[i];
+        L.id = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[i];
+    };
+    Loads cur{}, nxt{};
+    uint64_t b = lo + 2 * wave + h;                 // this lane half's block
+    if (b < hi) issue(b, cur);
+    for (; b - h < hi; b += 2 * nwaves) {           // the loop is wave-uniform: it runs while the pair's first block exists
+        const uint64_t bn = b + 2 * nwaves;
+        if (bn < hi) issue(bn, nxt);
+        const bool live = b < hi;
+        LaneEst v;
+        uint32_t S[BW];
+#pragma unroll
+        for (int k = 0; k < BW; ++k) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            acc4(cur.c[k].x, qm[0], a0, a1, a2, a3);
+            acc4(cur.c[k].y, qm[1], a0, a1, a2, a3);
+            acc4(cur.c[k].z, qm[2], a0, a1, a2, a3);
+            acc4(cur.c[k].w, qm[3], a0, a1, a2, a3);
+            S[k] = a0 + 2 * a1 + 4 * a2 + 8 * a3;
+        }
+        if constexpr (BW == 1) { v.nbit = v.msb = v.msb2 = S[0]; }
+        else { v.nbit = 2 * S[0] + S[1]; v.msb = S[0]; v.msb2 = 2 * S[0] + S[1]; }
+        v.nop = __uint_as_float(cur.aux.x);
+        v.ip_qo = __uint_as_float(cur.aux.y);
+        v.ip_cp = __uint_as_float(cur.aux.z);
+        v.pop = cur.aux.w & 0xFFFFu;
+        v.wpop = cur.aux.w >> 16;
+        float est, lower;
+        if constexpr (BW == 1) {
+            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+            if (live) acc += est + lower;
+        } else {
+            const float lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+            if (live) acc += est + lower + lo1;
+        }
+        if (live && cur.id == kInvalidNode) acc = 0.0f;    // the neighbour ids are part of the unit of work
+        if (a.out_est && live) {
+            a.out_est[(b - a.first) * 32 + i] = est;
+            a.out_lower[(b - a.first) * 32 + i] = lower;
+        }
+        cur = nxt;
+    }
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0 && !a.out_est) a.sink[wave] = acc;
+}
+
 // Parity hook: one block of a loaded index, all intermediate values.
 struct BlockHookArgs {
     const uint8_t* blk;

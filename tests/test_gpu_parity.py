@@ -121,6 +121,23 @@ def test_stream_blocks_match_oracle(cph, oracle, D, bits):
     ms, ck = st.run(2)
     assert ms > 0 and np.isfinite(ck)
     st.close()
+    if D == 128 and bits <= 2:
+        # the two-blocks-per-wave kernel of the narrow shapes: an odd block count and an odd first block
+        st = cph.FastScanStream(D, bits, 301, seed=11)
+        blocks, lut, qp, dqp = st.export(297, 4, nb_bytes)
+        est, lower = st.eval(297, 4)
+        for b in range(4):
+            nb = blocks.reshape(4, nb_bytes)[b]
+            planes = nb[L[2]:L[2] + bits * D * 4].reshape(bits, D // 8, 32)
+            nop, ipqo, ipcp = (nb[L[j]:L[j] + 128].view(np.float32) for j in (3, 4, 5))
+            pop = nb[L[6]:L[6] + 64].view(np.uint16)
+            if bits == 1:
+                e, lo = oracle.convert_1bit(D, qp, oracle.fastscan_plane(D, lut, planes[0]), nop, ipqo, ipcp, pop, dqp)
+            else:
+                s_, m_ = oracle.fastscan_nbit(D, bits, lut, planes)
+                e, lo = oracle.convert_nbit(D, bits, qp, s_, m_, nop, ipqo, ipcp, pop, nb[L[7]:L[7] + 64].view(np.uint16), dqp)
+            assert _beq(est[b], e) and _beq(lower[b], lo), (D, bits, b)
+        st.close()
 
 
 @pytest.mark.parametrize("name,bits,D,dim", [("g128", 1, 128, 128), ("sift96", 4, 128, 96),
@@ -384,3 +401,17 @@ def test_native_file_roundtrip(cph, gold, tmp_path, name, bits):
         ix3.load_native(fixture_path(name, bits))
     with pytest.raises(RuntimeError, match="mismatch"):
         cph.CPIndex(DATASETS[name]["dim"], 1 if bits != 1 else 2).load_native(pn)
+
+
+def test_torch_can_initialise_after_the_library():
+    """Process-level: our library first, torch.cuda afterwards (a PyTorch-ROCm wheel bundles its own HIP runtime;
+    cphnsw_mi355x._lib makes both use the same one)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import cphnsw_mi355x as c; s = c.FastScanStream(128, 4, 64); s.run(1); s.close(); "
+            "import torch; torch.cuda.init(); assert torch.cuda.device_count() >= 1; "
+            "x = torch.ones(8, device='cuda').sum().item(); assert x == 8.0; print('OK')") % os.path.join(root, "rabitq-ann-search_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
