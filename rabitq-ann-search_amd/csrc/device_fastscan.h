@@ -40,12 +40,22 @@ struct LaneEst {      // per-lane (neighbour i = lane & 31) results, valid on al
 __device__ __forceinline__ float vmaxf(float a, float b) { return a > b ? a : b; }  // _mm256_max_ps
 __device__ __forceinline__ float vminf(float a, float b) { return a < b ? a : b; }  // _mm256_min_ps
 
+// popcount(x) + acc in ONE instruction: v_bcnt_u32_b32 has an accumulate operand.  Written as inline assembly
+// because the compiler, given `acc += __popc(x)`, emits the popcounts with a zero addend and then re-associates
+// the sums into a tree of v_add3 (shorter chains, a quarter more instructions -- and this kernel is bound by
+// instruction issue, not by latency: four independent accumulators are interleaved anyway).
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ void acc4(uint32_t c, uint4 q, uint32_t& a0, uint32_t& a1,
                                      uint32_t& a2, uint32_t& a3) {
-    a0 += __popc(c & q.x);
-    a1 += __popc(c & q.y);
-    a2 += __popc(c & q.z);
-    a3 += __popc(c & q.w);
+    a0 = bcnt_acc(c & q.x, a0);
+    a1 = bcnt_acc(c & q.y, a1);
+    a2 = bcnt_acc(c & q.z, a2);
+    a3 = bcnt_acc(c & q.w, a3);
 }
 
 // Integer sums of one block.  qm = LDS, uint4 per 32-dim word: {Q0,Q1,Q2,Q3}.

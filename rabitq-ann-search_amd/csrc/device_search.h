@@ -139,8 +139,12 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) float lds_f32;
 
 struct Beam {
+    typedef uint4 E;
     lds_u32x4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
     uint4* g;       // global, [cap], indexed by heap index
+    // the heap's comparator (std::greater on est: a min-heap) and the key of an entry
+    static __device__ __forceinline__ bool before(float a, float b) { return a > b; }
+    static __device__ __forceinline__ float key_of(uint4 e) { return __uint_as_float(e.x); }
     __device__ __forceinline__ uint4 lds(uint32_t i) const {
         const u32x4 t = l[i];
         return make_uint4(t.x, t.y, t.z, t.w);
@@ -166,6 +170,30 @@ struct Beam {
         return BeamEntry{__uint_as_float(v.x), __uint_as_float(v.y), v.z};
     }
 };
+
+// The result heap (BoundedMaxHeap, rabitq_search.hpp:17-49) as the wave-parallel heap routines see it: k entries
+// {id, dist} of 8 bytes in LDS, comparator std::less on dist (a max-heap).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+struct NnLds {
+    typedef uint2 E;
+    lds_u32x2* l;
+    static __device__ __forceinline__ bool before(float a, float b) { return a < b; }
+    static __device__ __forceinline__ float key_of(uint2 e) { return __uint_as_float(e.y); }
+    __device__ __forceinline__ uint2 lds(uint32_t i) const {
+        const u32x2 t = l[i];
+        return make_uint2(t.x, t.y);
+    }
+    __device__ __forceinline__ void lds_put(uint32_t i, uint2 v) const {
+        u32x2 t;
+        t.x = v.x; t.y = v.y;
+        l[i] = t;
+    }
+    __device__ __forceinline__ float lds_key(uint32_t i) const {
+        return reinterpret_cast<lds_f32*>(l)[2 * i + 1];
+    }
+};
+constexpr uint32_t kWaveHeapMax = 256;   // largest heap the wave-parallel pop handles (two ballot masks)
 
 __device__ __forceinline__ uint4 beam_pack(const BeamEntry& e) {
     return make_uint4(__float_as_uint(e.est), __float_as_uint(e.lower), e.id, 0u);
@@ -209,16 +237,17 @@ __device__ __forceinline__ void beam_adjust(const Beam& h, uint32_t hole, uint32
 // wave-uniform bit masks with no memory access, and the moves along the path are one parallel
 // LDS read plus one parallel write.  Two LDS round trips instead of one dependent round trip
 // per heap level.
-__device__ __forceinline__ void beam_pop_wave(const Beam& h, uint32_t size, int lane) {
+template <class H>
+__device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lane) {
     const uint32_t len = size - 1;                // heap length once the last element is taken out
-    const uint4 v = h.lds(len);                   // the value __adjust_heap re-inserts
+    const typename H::E v = h.lds(len);            // the value __adjust_heap re-inserts
     const uint32_t nint = (len - 1) >> 1;         // nodes j < nint have both children below len
     bool b0 = false, b1 = false;                  // true: the left child moves up
-    if ((uint32_t)lane < nint) b0 = h.lds_key(2 * lane + 2) > h.lds_key(2 * lane + 1);
+    if ((uint32_t)lane < nint) b0 = H::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1));
     const unsigned long long m0 = __ballot(b0);
     unsigned long long m1 = 0;
     if (nint > 64) {
-        if ((uint32_t)lane + 64 < nint) b1 = h.lds_key(2 * lane + 130) > h.lds_key(2 * lane + 129);
+        if ((uint32_t)lane + 64 < nint) b1 = H::before(h.lds_key(2 * lane + 130), h.lds_key(2 * lane + 129));
         m1 = __ballot(b1);
     }
     // Walk on hp = hole + 1: taking the left child doubles it, the right child doubles it and adds 1,
@@ -266,17 +295,70 @@ __device__ __forceinline__ void beam_pop_wave(const Beam& h, uint32_t size, int 
     const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
     const uint32_t my_dst = (hp >> (d - t)) - 1;                    // p_t: lane t moves entry p_{t+1} into it
     const uint32_t my_src = (hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u))) - 1;   // p_{t+1}
-    uint4 e = make_uint4(0, 0, 0, 0);
+    typename H::E e = v;
     bool c = false;                                // __push_heap: parent (now e_t) > v -> parent moves down
     if ((uint32_t)lane < d) {
         e = h.lds(my_src);
-        c = __uint_as_float(e.x) > __uint_as_float(v.x);
+        c = H::before(H::key_of(e), H::key_of(v));
     }
     const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
     const uint32_t fin = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;   // v ends at p_fin
     if ((uint32_t)lane < fin) h.lds_put(my_dst, e);
     if (fin == d) { if (lane == 0) h.lds_put(hole, v); }
     else if ((uint32_t)lane == fin) h.lds_put(my_dst, v);
+}
+
+// std::push_heap of `v` at index `hole` (= the heap's size before the push) for a beam that stays inside the LDS
+// levels, executed by the whole wave.  libstdc++'s __push_heap moves the hole up while the parent compares greater
+// than the value; the ancestors of a leaf are known from its index alone -- p_t = ((hole + 1) >> t) - 1 -- so lane
+// t - 1 reads ancestor p_t, all comparisons are made at once, the number of leading "parent moves down" answers m is
+// a ballot and a count, and the moves are one parallel write: ancestors 1..m each drop one step along the path, the
+// value lands on p_m.  One LDS read round trip and one write instead of one dependent round trip per heap level.
+template <class H>
+__device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typename H::E v, int lane) {
+    const uint32_t hp = hole + 1;
+    const uint32_t depth = 31u - (uint32_t)__builtin_clz(hp);          // ancestors of the leaf (0 for the root)
+    const uint32_t t = (uint32_t)lane + 1;                              // lane t - 1 looks at ancestor p_t
+    const bool on = t <= depth;
+    const uint32_t pt = on ? (hp >> t) - 1 : 0u;
+    typename H::E e = v;
+    bool down = false;
+    if (on) {
+        e = h.lds(pt);
+        down = H::before(H::key_of(e), H::key_of(v));
+    }
+    const unsigned long long stop = ~__ballot(down);                   // first ancestor that stays (bits >= depth are set)
+    const uint32_t m = (uint32_t)__builtin_ctzll(stop);                 // ancestors p_1..p_m move down
+    if (t <= m) h.lds_put((hp >> (t - 1)) - 1, e);                      // p_t's entry to p_(t-1), p_0 = the leaf
+    if ((uint32_t)lane == m) h.lds_put((hp >> m) - 1, v);              // (m <= depth <= 8 < 64: that lane exists)
+}
+
+// BoundedMaxHeap::push (rabitq_search.hpp:26-35) by the whole wave; every argument is wave-uniform, `top` is the
+// heap's current root key.  Same element movement as nn_push (which stays as the path for heaps too large for
+// the two ballot masks of the wave-parallel pop).
+__device__ __forceinline__ void nn_push_wave(const NnLds& w, Result* h, uint32_t& size, uint32_t k, uint32_t id, float dist,
+                                             float top, int lane) {
+    const uint2 r = make_uint2(id, __float_as_uint(dist));
+    if (size < k) {
+        if (size < kWaveHeapMax) {
+            heap_push_wave(w, size, r, lane);
+        } else {
+            if (lane == 0) nn_sift_up(h, size, 0, Result{id, dist});
+            __builtin_amdgcn_wave_barrier();
+        }
+        ++size;
+    } else if (dist < top) {
+        if (size <= kWaveHeapMax) {
+            if (size > 1) heap_pop_wave(w, size, lane);        // std::pop_heap: the old last value sinks in from the root
+            heap_push_wave(w, size - 1, r, lane);              // back() = r; std::push_heap
+        } else {
+            if (lane == 0) {
+                nn_adjust(h, 0, size - 1, h[size - 1]);
+                nn_sift_up(h, size - 1, 0, Result{id, dist});
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v) {
@@ -340,6 +422,8 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     float* s_slack = reinterpret_cast<float*>(fixed + 960);
     double* s_ratio = reinterpret_cast<double*>(fixed + 1088);   // [2]
     Result* nn = reinterpret_cast<Result*>(fixed + kLdsFixed);
+    NnLds nnw;
+    nnw.l = (lds_u32x2*)(fixed + kLdsFixed);
     // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
     const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
     lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
@@ -432,26 +516,26 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
         __syncthreads();
 
         for (;;) {
-            // ---- pop + termination tests (lane 0) (:106-122) --------------------------
+            // ---- termination tests on the beam's top (:106-122); the pop itself comes later -----
             CPH_TICK(7);
             if (beam_size == 0) break;
             uint32_t cur_id;
-            float worst_pop;   // result-heap threshold as read by the pop (wave-uniform)
-            {
-                // every LDS read the pop needs first goes out together: the top, the result-heap
-                // threshold, and (inside beam_pop_wave) the re-inserted entry and the child keys
-                const uint4 topv = heap.lds(0);
-                const float worst = nn_size ? nn[0].dist : FMAX;
-                if (beam_size > 1) {
-                    if (beam_size <= kBeamLds) {
-                        beam_pop_wave(heap, beam_size, lane);
+            float worst_pop;   // result-heap threshold as read here (wave-uniform)
+            // std::pop_heap of the beam (whole wave while it lives in LDS, lane 0 once it has spilled)
+            auto pop_beam = [&](uint32_t size) {
+                if (size > 1) {
+                    if (size <= kBeamLds) {
+                        heap_pop_wave(heap, size, lane);
                     } else {
-                        if (lane == 0) beam_adjust(heap, 0, beam_size - 1, heap.raw(beam_size - 1));
+                        if (lane == 0) beam_adjust(heap, 0, size - 1, heap.raw(size - 1));
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
+            };
+            {
+                const uint4 topv = heap.lds(0);
+                const float worst = nn_size ? nn[0].dist : FMAX;
                 cur_id = bcast_u32(topv.z);
-                --beam_size;
                 const float cur_est = __uint_as_float(topv.x);
                 const float cur_lower = __uint_as_float(topv.y);
                 uint32_t verdict = 2;  // 0 = done, 1 = skip (lower-bound pruned), 2 = expand
@@ -459,7 +543,11 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 else if (nn_size >= k && cur_lower > worst) verdict = 1;
                 verdict = bcast_u32(verdict);   // every lane read the same words: make it provably uniform
                 if (verdict == 0) break;
-                if (verdict == 1) continue;
+                if (verdict == 1) {             // pruned: the entry leaves the beam, nothing is loaded
+                    pop_beam(beam_size);
+                    --beam_size;
+                    continue;
+                }
                 worst_pop = bcast_f32(worst);
             }
             CPH_TICK(0);
@@ -485,6 +573,13 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
             bl.issue(blk, a.L, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the pop, while those loads are in flight.  It needs only the id of the top, which the loads
+            // above already have; its three dependent LDS round trips and its scalar path walk (a fifth of an
+            // expansion's time when it ran in front of the loads) now hide behind the block's memory latency.
+            // LDS and scalar work only (lgkmcnt), so no wait on the loads (vmcnt) is forced here.
+            pop_beam(beam_size);
+            --beam_size;
             __builtin_amdgcn_sched_barrier(0);
             // All of this expansion's loads come back together (issued back to back, retired in
             // order); they are retired HERE, before the probe goes out.  The probe is only issued when
@@ -542,10 +637,9 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             float worst0 = worst_pop;
             const bool nn_changes = bcast_u32((nn_size < k || exact_dist < worst_pop) ? 1u : 0u) != 0u;   // provably uniform
             if (nn_changes) {
-                if (lane == 0) nn_push(nn, nn_size, k, Result{cur_id, exact_dist});
-                nn_size = bcast_u32(nn_size);
+                nn_push_wave(nnw, nn, nn_size, k, cur_id, exact_dist, worst_pop, lane);
                 __builtin_amdgcn_wave_barrier();
-                worst0 = bcast_f32(nn_size ? nn[0].dist : FMAX);
+                worst0 = bcast_f32(nn_size ? nnw.lds_key(0) : FMAX);
             }
             const uint32_t nn_sz = nn_size;
             CPH_TICK(1);
@@ -675,7 +769,12 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                         const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
                         const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
                         const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
-                        if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
+                        if (beam_size < kBeamLds) {
+                            heap_push_wave(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
+                        } else {
+                            if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
+                            __builtin_amdgcn_wave_barrier();
+                        }
                         ++beam_size;
                         ++st_push;
                     }
@@ -685,61 +784,64 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
                 // entry fails it at its turn too (:241), so those neighbours are dropped here
                 uint32_t m = warmup ? new_mask
                                     : new_mask & (uint32_t)(__ballot(!(lower >= worst0)) & 0xFFFFFFFFull);
+                // Every quantity of the reference's loop body is wave-uniform here (neighbour i's values come out
+                // of lane i with v_readlane, the heaps live in LDS), so the whole wave walks the loop together and
+                // the heap operations are the wave-parallel ones: a rerank costs two LDS round trips per heap
+                // operation instead of one dependent round trip per heap level on lane 0.
                 while (m) {
                     const int i = __ffs((int)m) - 1;
                     m &= m - 1;
                     const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
                     const float e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i));
                     const float lo_i = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i));
-                    if (lane == 0) {
-                        float worst = nn_size ? nn[0].dist : FMAX;
-                        const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
-                        float key = 0.0f, lo = lo_i;
-                        bool push = false;
-                        if (warmup) {
-                            const float ex = s_exact[i];
-                            nn_push(nn, nn_size, k, Result{id_i, ex});
-                            if (ex < dabs) { push = true; key = ex; lo = ex; }
-                        } else if (!(lo_i >= worst)) {
-                            if (e < worst) {
-                                const float ex = s_exact[i];
-                                nn_push(nn, nn_size, k, Result{id_i, ex});
-                                if (ex < dabs) { push = true; key = ex; }
-                                if (ex > kEpsSmall) {
-                                    // gamma adaptation (:255-267), fused as the reference compiles it
-                                    double r = (double)(e / ex);
-                                    const double rs = s_ratio[0] + r;
-                                    const double rq = fma(r, r, s_ratio[1]);
-                                    s_ratio[0] = rs;
-                                    s_ratio[1] = rq;
-                                    ++ratio_count;
-                                    if (ratio_count >= a.sc.gamma_warmup) {
-                                        double cnt = (double)ratio_count;
-                                        double mean = rs / cnt;
-                                        double var = fma(-mean, mean, rq / cnt);
-                                        double sd = sqrt(var < 0.0 ? 0.0 : var);
-                                        float gq = gamma * (float)fma((double)a.sc.gamma_beta, sd, 1.0);
-                                        gamma_q = (gq < gamma) ? gamma
-                                                               : ((a.sc.gamma_max < gq) ? a.sc.gamma_max : gq);
-                                    }
+                    const float worst = bcast_f32(nn_size ? nnw.lds_key(0) : FMAX);
+                    const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
+                    // 1 = rerank (result-heap push), 4 = ... and feed the gamma adaptation, 2 = DABS enqueue on the estimate
+                    uint32_t act = 0;
+                    if (warmup) act = 1;
+                    else if (!(lo_i >= worst)) act = (e < worst) ? 5u : ((e < dabs) ? 2u : 0u);
+                    act = bcast_u32(act);
+                    float key = e, lo = lo_i;
+                    bool push = (act & 2u) != 0;
+                    if (act & 1u) {
+                        const float ex = bcast_f32(s_exact[i]);
+                        nn_push_wave(nnw, nn, nn_size, k, id_i, ex, worst, lane);
+                        if (ex < dabs) { push = true; key = ex; if (warmup) lo = ex; }
+                        if ((act & 4u) && ex > kEpsSmall) {
+                            // gamma adaptation (:255-267), fused as the reference compiles it; fp64 on one lane
+                            ++ratio_count;
+                            if (lane == 0) {
+                                double r = (double)(e / ex);
+                                const double rs = s_ratio[0] + r;
+                                const double rq = fma(r, r, s_ratio[1]);
+                                s_ratio[0] = rs;
+                                s_ratio[1] = rq;
+                                if (ratio_count >= a.sc.gamma_warmup) {
+                                    double cnt = (double)ratio_count;
+                                    double mean = rs / cnt;
+                                    double var = fma(-mean, mean, rq / cnt);
+                                    double sd = sqrt(var < 0.0 ? 0.0 : var);
+                                    float gq = gamma * (float)fma((double)a.sc.gamma_beta, sd, 1.0);
+                                    gamma_q = (gq < gamma) ? gamma
+                                                           : ((a.sc.gamma_max < gq) ? a.sc.gamma_max : gq);
                                 }
-                            } else if (e < dabs) {
-                                push = true;
-                                key = e;
                             }
-                        }
-                        if (push) {
-                            beam_sift_up(heap, beam_size, 0, beam_pack(BeamEntry{key, lo, id_i}));
-                            ++beam_size;
-                            ++st_push;
+                            gamma_q = bcast_f32(gamma_q);
                         }
                     }
+                    if (bcast_u32(push ? 1u : 0u)) {
+                        const uint4 ent = beam_pack(BeamEntry{key, lo, id_i});
+                        if (beam_size < kBeamLds) {
+                            heap_push_wave(heap, beam_size, ent, lane);
+                        } else {
+                            if (lane == 0) beam_sift_up(heap, beam_size, 0, ent);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        ++beam_size;
+                        ++st_push;
+                    }
                 }
-                // the serial state lives on lane 0: make it wave-uniform again
-                beam_size = bcast_u32(beam_size);
-                nn_size = bcast_u32(nn_size);
-                gamma_q = bcast_f32(gamma_q);
-                st_push = bcast_u32(st_push);
+                CPH_TICK(4);      // (timer builds: the serial replay is booked with the speculative rerank)
             }
             CPH_TICK(5);
             log_count += n_new;
