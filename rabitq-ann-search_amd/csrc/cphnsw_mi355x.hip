@@ -77,20 +77,19 @@ void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, s
     for (auto& x : th) x.join();
 }
 
-// kernel dispatch over (bits, static D): D == 128 gets the fully unrolled instantiation
+// kernel dispatch over (bits, static D): D == 128 and D == 1024 (the BASELINE shapes) get instantiations with a
+// compile-time D -- every code load of a block in flight at once, the vertex vector through LDS-DMA
+#define CPH_LAUNCH_BITS(KERNEL, bits, SDV, grid, block, lds, st, args)                            \
+    do {                                                                                          \
+        if ((bits) == 1) hipLaunchKernelGGL((KERNEL<1, SDV>), grid, block, lds, st, args);        \
+        else if ((bits) == 2) hipLaunchKernelGGL((KERNEL<2, SDV>), grid, block, lds, st, args);   \
+        else hipLaunchKernelGGL((KERNEL<4, SDV>), grid, block, lds, st, args);                    \
+    } while (0)
 #define CPH_LAUNCH(KERNEL, bits, D, grid, block, lds, st, args)                                   \
     do {                                                                                          \
-        const bool s128 = (D) == 128;                                                             \
-        if ((bits) == 1) {                                                                        \
-            if (s128) hipLaunchKernelGGL((KERNEL<1, 128>), grid, block, lds, st, args);           \
-            else hipLaunchKernelGGL((KERNEL<1, 0>), grid, block, lds, st, args);                  \
-        } else if ((bits) == 2) {                                                                 \
-            if (s128) hipLaunchKernelGGL((KERNEL<2, 128>), grid, block, lds, st, args);           \
-            else hipLaunchKernelGGL((KERNEL<2, 0>), grid, block, lds, st, args);                  \
-        } else {                                                                                  \
-            if (s128) hipLaunchKernelGGL((KERNEL<4, 128>), grid, block, lds, st, args);           \
-            else hipLaunchKernelGGL((KERNEL<4, 0>), grid, block, lds, st, args);                  \
-        }                                                                                         \
+        if ((D) == 128) CPH_LAUNCH_BITS(KERNEL, bits, 128, grid, block, lds, st, args);           \
+        else if ((D) == 1024) CPH_LAUNCH_BITS(KERNEL, bits, 1024, grid, block, lds, st, args);    \
+        else CPH_LAUNCH_BITS(KERNEL, bits, 0, grid, block, lds, st, args);                        \
         HIP_CHECK(hipGetLastError());                                                             \
     } while (0)
 
@@ -471,7 +470,12 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     HIP_CHECK(hipMemsetAsync(s.d_stats.p, 0, kStatWords * 8, st));
     // resident query slots: one wave each
     uint32_t wpc = h->waves_per_cu;
-    if (!h->waves_from_env) wpc = 4 * (h->L.D == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD);
+    if (!h->waves_from_env) {
+        // registers (launch bounds of the instantiation) and LDS (160 KB per CU) both cap the resident waves
+        wpc = 4 * (uint32_t)search_waves_per_simd(search_static_d(h->L.D) ? (int)h->L.D : 0);
+        const size_t lds_wave = search_lds_bytes(h->L.D, h->L.PW, k);
+        wpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(wpc, (160u * 1024u) / lds_wave));
+    }
     const uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc;
     // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
     // would leave 56% of the slots idle during the third round)
@@ -1204,7 +1208,10 @@ void stream_launch(cph_stream* s, float* out_est, float* out_lower, uint64_t fir
         HIP_CHECK(hipGetLastError());
         return;
     }
-    CPH_LAUNCH(fastscan_stream_kernel, s->L.BW, s->L.D, dim3(grid), dim3(256), (size_t)s->L.PW * 16, st, a);
+    // (the instantiation with a compile-time D = 1024 holds a whole 16-KB block in registers twice over and loses
+    // its occupancy: 0.63 against 0.75 of peak for the runtime-D loop -- the stream kernel uses the latter there)
+    const uint32_t dsel = s->L.D == 128 ? 128u : 0u;
+    CPH_LAUNCH(fastscan_stream_kernel, s->L.BW, dsel, dim3(grid), dim3(256), (size_t)s->L.PW * 16, st, a);
 }
 
 }  // namespace

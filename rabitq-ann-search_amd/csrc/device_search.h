@@ -368,12 +368,16 @@ __device__ __forceinline__ float bcast_f32(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 }
 
-// LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512] (popped vertex's vector, LDS-DMA target) |
+// LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512 or D*4] (popped vertex's vector, LDS-DMA target) |
 // pf[256] (prefetch sink, latency mode) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsFixed = 512 + 256 + 128 + 64 + 128 + 16;
+constexpr uint32_t kLdsTail = 256 + 128 + 64 + 128 + 16;      // pf | exact | list | slack | ratio
+// vec[] holds the popped vertex' whole vector in the instantiations with a compile-time D (LDS-DMA target)
+__host__ __device__ inline uint32_t search_vec_bytes(uint32_t D, bool static_d) { return static_d ? D * 4 : 512; }
+__host__ __device__ inline bool search_static_d(uint32_t D) { return D == 128 || D == 1024; }
 __host__ __device__ inline size_t search_lds_bytes(uint32_t D, uint32_t PW, uint32_t k) {
-    return (size_t)PW * 16 + (size_t)D * 4 + kLdsFixed + (((size_t)k * 8 + 15) & ~(size_t)15) + 16 * (kBeamLds + 1);
+    return (size_t)PW * 16 + (size_t)D * 4 + search_vec_bytes(D, search_static_d(D)) + kLdsTail +
+           (((size_t)k * 8 + 15) & ~(size_t)15) + 16 * (kBeamLds + 1);
 }
 
 // LDS-DMA loads (global -> LDS, no VGPR destination), written as inline assembly on purpose: hipcc
@@ -397,7 +401,6 @@ __device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_off) : "memory");
 }
 
-template <int BW, int SD>
 // Waves per SIMD: 6 (<= 80 VGPRs) for the static D = 128 instantiations, 5 (<= 96 VGPRs) for the
 // generic ones -- measured on MI355X
 #ifndef CPH_SEARCH_WAVES_PER_SIMD
@@ -406,7 +409,16 @@ template <int BW, int SD>
 #ifndef CPH_SEARCH_WAVES_PER_SIMD_128
 #define CPH_SEARCH_WAVES_PER_SIMD_128 6
 #endif
-__global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CPH_SEARCH_WAVES_PER_SIMD)) void search_kernel(SearchArgs a) {
+// D = 1024: the whole block's codes (up to 16 x 16 B per lane) are in flight at once: 2 waves per SIMD (3 spill:
+// 7.4 against 5.2 ms per 1,000 queries at C3); LDS (query + vertex vector, 4 KB each) allows 11 per CU anyway
+#ifndef CPH_SEARCH_WAVES_PER_SIMD_1024
+#define CPH_SEARCH_WAVES_PER_SIMD_1024 2
+#endif
+__host__ __device__ constexpr int search_waves_per_simd(int sd) {
+    return sd == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : (sd == 1024 ? CPH_SEARCH_WAVES_PER_SIMD_1024 : CPH_SEARCH_WAVES_PER_SIMD);
+}
+template <int BW, int SD>
+__global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int li = lane & 31;
@@ -417,22 +429,23 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
     float* qv = reinterpret_cast<float*>(smem + (size_t)PW * 16);
     unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
     float* s_vec = reinterpret_cast<float*>(fixed);
-    float* s_exact = reinterpret_cast<float*>(fixed + 768);
-    uint8_t* s_list = fixed + 896;
-    float* s_slack = reinterpret_cast<float*>(fixed + 960);
-    double* s_ratio = reinterpret_cast<double*>(fixed + 1088);   // [2]
-    Result* nn = reinterpret_cast<Result*>(fixed + kLdsFixed);
+    constexpr uint32_t vsz = SD >= 128 ? (uint32_t)SD * 4u : 512u;
+    float* s_exact = reinterpret_cast<float*>(fixed + vsz + 256);
+    uint8_t* s_list = fixed + vsz + 384;
+    float* s_slack = reinterpret_cast<float*>(fixed + vsz + 448);
+    double* s_ratio = reinterpret_cast<double*>(fixed + vsz + 576);   // [2]
+    Result* nn = reinterpret_cast<Result*>(fixed + vsz + kLdsTail);
     NnLds nnw;
-    nnw.l = (lds_u32x2*)(fixed + kLdsFixed);
+    nnw.l = (lds_u32x2*)(fixed + vsz + kLdsTail);
     // the beam's LDS levels, 16-B aligned, addressed as LDS (address space 3)
-    const uint32_t beam_off = PW * 16 + D * 4 + kLdsFixed + ((k * 8 + 15) & ~15u);
+    const uint32_t beam_off = PW * 16 + D * 4 + vsz + kLdsTail + ((k * 8 + 15) & ~15u);
     lds_u32x4* s_beam = (lds_u32x4*)(smem + beam_off);
 
     // LDS byte offset of s_vec for the DMA's M0: the dynamic LDS starts right behind the kernel's static
     // LDS (none here), so this is a compile-time constant -- a generic-to-LDS pointer cast would be
     // re-derived (with its null check) by ten scalar instructions in every expansion
     const uint32_t vec_off = __builtin_amdgcn_groupstaticsize() + PW * 16 + D * 4;
-    const uint32_t pf_off = vec_off + 512;
+    const uint32_t pf_off = vec_off + vsz;
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
     uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
@@ -567,6 +580,10 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             if constexpr (SD == 128) {
                 if (lane < 32) lds_dma16(vrow + 4 * lane, vec_off);
                 __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (SD > 128) {
+#pragma unroll
+                for (int c = 0; c < SD / 256; ++c) lds_dma16(vrow + 4 * lane + 256 * c, vec_off + 1024 * c);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float norm_ld = a.norm_sq[cur_id];
             const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             uint32_t nid = nid_ld;
             float cur_norm = norm_ld;
             float dot_generic = 0.0f;
-            if constexpr (SD != 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
+            if constexpr (SD < 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
             bl.retire();
             asm volatile("" : "+v"(cur_norm), "+v"(nid));
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
@@ -625,7 +642,7 @@ __global__ __launch_bounds__(64, (SD == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : CP
             float exact_dist;
             {
                 float dot;
-                if constexpr (SD == 128) dot = bcast_f32(group_reduce8_lo(chain_dot_lds<16>(qv, s_vec, lane & 7, 0.0f)));
+                if constexpr (SD >= 128) dot = bcast_f32(group_reduce8_lo(chain_dot_lds<SD / 8>(qv, s_vec, lane & 7, 0.0f)));
                 else dot = dot_generic;
                 exact_dist = exact_from_dot(qnorm, cur_norm, dot);
             }
