@@ -158,7 +158,6 @@ struct cph_index {
     int last_search = -1;              // the set the most recent search went to
     hipStream_t own_stream = nullptr;  // host-API calls (cph_search_batch, cph_search, hooks)
     bool order_queries = true;         // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
-    uint32_t lat_queries = 0;          // head of the launch order that runs with the next-top prefetch (CPH_LAT_QUERIES)
     // knobs
     uint32_t want_slots = 0;
     uint64_t want_cap = 0;
@@ -429,7 +428,6 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     if (!rerun) {
         a.todo = d_todo;
         a.nq = nq;
-        a.lat_count = d_todo ? h->lat_queries : 0u;
         a.counter = words;
         a.cap = s.cap;
         a.bitmaps = s.d_bitmaps.p;
@@ -565,7 +563,6 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
-        if (const char* e = getenv("CPH_LAT_QUERIES")) h->lat_queries = (uint32_t)std::max(0, atoi(e));
         if (const char* e = getenv("CPH_WAVES_PER_CU")) { h->waves_per_cu = (uint32_t)std::max(1, atoi(e)); h->waves_from_env = true; }
         *out = h;
     });

@@ -48,7 +48,6 @@ struct SearchArgs {
     const uint32_t* todo;   // optional: query indices to run (launch order / re-run list), else 0..nq-1
     uint32_t nq;
     const uint32_t* nq_dev; // optional: the batch size lives in device memory (the overflow re-run's list length)
-    uint32_t lat_count;     // the first lat_count queries of the launch order run in latency mode (next-top prefetch)
     uint32_t k;
     SearchConsts sc;
     // work queue + per-slot scratch
@@ -460,7 +459,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     // (:124-128).  With a queue behind the slots that prefetch only costs bandwidth (see below).
     // (Switching to it when a larger batch starts to drain was tried: any way of telling thousands of
     // running waves that the queue is empty -- polling the counter or a flag word -- cost far more than
-    // the prefetch gains in the drain phase.)
+    // the prefetch gains in the drain phase.  So was a per-query latency mode for the head of the launch
+    // order -- the longest queries -- or for its tail -- the ones that start as the queue runs dry: both
+    // 1-4 % slower on the 10k batch, profiles/r2_lat_sweep.jsonl.)
     const uint32_t nq = a.nq_dev ? *a.nq_dev : a.nq;
     const bool lat = nq <= gridDim.x;
     for (;;) {
@@ -469,9 +470,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
         t = bcast_u32(t);
         if (t >= nq) break;
         const uint32_t qi = a.todo ? a.todo[t] : t;
-        // The launch order hands the longest queries out first: they are the batch's critical path once the
-        // queue has run dry, so they -- and only they -- get the prefetch of the next beam top.
-        const bool lat_q = lat || t < a.lat_count;
 
         for (uint32_t w = lane; w < PW; w += 64) qm[w] = a.qmasks[(size_t)qi * PW + w];
         for (uint32_t d = lane; d < D; d += 64) qv[d] = a.queries[(size_t)qi * D + d];
@@ -625,7 +623,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
             // bandwidth that is the scarcer resource there (22.9 -> 21.1 ms per 100k queries without).
             // The compiler does not know this load: it goes right behind the probe, the only load of
             // this expansion still to be waited for (with vmcnt(0)).
-            if (lat_q && beam_size > 0) {
+            if (lat && beam_size > 0) {
                 const uint32_t next_id = bcast_u32(heap.lds(0).z);
                 const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
                 const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;

@@ -1,5 +1,6 @@
-"""A/B of the per-query latency mode (CPH_LAT_QUERIES = head of the launch order that prefetches its next beam
-top) on the cached bench index: kernel time of serialised 10k-query batches and two-stream throughput."""
+"""Timing tool on the cached bench index: kernel time of serialised batches and two-stream throughput, one line
+per entry of the comma-separated list (historically: a CPH_LAT_QUERIES knob that no longer exists; the list now
+just repeats the measurement).  CPH_LIB_PATH selects a variant library."""
 import os, sys, time, json
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
