@@ -160,16 +160,26 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         fetch(ntl, nch);
         const float* Qb = Qs[buf];
         const float* Bb = Bs[buf];
+        // All 20 operand reads of the chunk are issued before the first of its 64 MFMAs: one exposed LDS round trip
+        // per chunk instead of one in front of every group of four (with one wave per SIMD nothing else would
+        // cover them).
+        knn_f32x4 av[4], bv[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const knn_f32x4 av = *reinterpret_cast<const knn_f32x4*>(&Qb[(wrow + c) * kKnnLd + 8 * j + 4 * h]);
+            av[j] = *reinterpret_cast<const knn_f32x4*>(&Qb[(wrow + c) * kKnnLd + 8 * j + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                bv[j][t] = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink every read back in front of its first use)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const knn_f32x4 bv = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j][t].w, acc[t], 0, 0, 0);
             }
         }
         // The other image was last read one chunk ago and every wave has passed a barrier since: it can
