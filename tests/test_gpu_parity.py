@@ -65,6 +65,9 @@ def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
         olut, oco, _ = oracle.encode_query(Q[qi], D)
         assert np.array_equal(lut, olut) and _beq(co, oco)
         assert ix.entry_point(Q[qi]) == oi.entry_point(Q[qi])
+        if qi == 0:   # the upper-layer descent (a12) for every query of the fixture, not just these three
+            for q in Q:
+                assert ix.entry_point(q) == oi.entry_point(q)
         for qp_tail, dqp in (((1.0, 0.0, 0.0, 0.1), 37.5), ((0.93, 0.02, 0.55, -0.05), 2.5e3),
                              ((1.0, 0.0, 0.0, 0.0), 0.0), ((1.0, 0.0, 0.0, 0.3), 5e-13)):
             qp = np.array([co[0], co[1], co[2], *qp_tail], np.float32)
