@@ -235,6 +235,9 @@ def pmc_traffic_ratio(config, k):
     return rec.get("hbm_bytes_over_algorithmic")
 
 
+STEP_TIMES = os.environ.get("CPH_BENCH_STEP_TIMES") == "1"
+
+
 def bench_stream_c5(args, local, world, rank, use_dist, dist, dev):
     """C5: streaming FastScan over the largest D=1024 / 2-bit block set that fits this GPU.
     Blocks only (random valid codes / aux), one encoded query, both N-bit stages per block."""
@@ -396,15 +399,26 @@ def main():
         return ids, d
 
     def timed(steps, serial):
+        # one untimed pass over each stream / scratch set first (allocator pools, RCCL's per-stream state): what a
+        # serving process has done long before its first batch; then the W warm-up steps proper
+        for i in range(2):
+            step(i, serial)
+        torch.cuda.synchronize()
         for i in range(args.warmup):
             step(i, serial)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = []
         for i in range(steps):
             ids, d = step(i, serial)
+            if STEP_TIMES:
+                marks.append(time.perf_counter() - t0)
         torch.cuda.synchronize()
+        if STEP_TIMES:
+            log("[bench] host time at the end of each step's enqueue (ms): " + " ".join(f"{1e3 * m:.2f}" for m in marks)
+                + f" | drained {1e3 * (time.perf_counter() - t0):.2f}")
         if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -456,7 +470,7 @@ def main():
 
     if rank == 0:
         ids_np = ids.cpu().numpy()
-        kname = f"search_kernel<{bits},{D if D == 128 else 0}>"
+        kname = f"search_kernel<{bits},{D if D in (128, 1024) else 0}>"
         gate = bool(recall and recall.get(f"k{k_run}_dedup", 0.0) >= 0.95)
         out = {
             "metric": "qps (search_batch_device, layer-0 hot path end to end) + fastscan_dist_per_s",

@@ -462,6 +462,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     // the prefetch gains in the drain phase.  So was a per-query latency mode for the head of the launch
     // order -- the longest queries -- or for its tail -- the ones that start as the queue runs dry: both
     // 1-4 % slower on the 10k batch, profiles/r2_lat_sweep.jsonl.)
+    // What bounds the throughput phase is instruction issue, not latency: per expansion a wave issues ~320 vector and
+    // ~270 scalar instructions (profiles/r2_pmc_search_summary.txt), and with six waves on a SIMD that is ~85 % of
+    // the SIMD's vector issue slots (one wave64 instruction per four cycles) while the queue is full.  Hiding more
+    // latency per wave therefore buys nothing -- tried and measured on one box: issuing the next expansion's loads
+    // before this expansion's beam pushes (the next top is known without doing them) 2.36 -> 2.46 ms per 10k
+    // queries; doing the same at a second issue site made the register allocator copy the loaded registers at the
+    // loop head, i.e. wait for them: 2.50 ms.  Fewer instructions per expansion is the only lever left.
     const uint32_t nq = a.nq_dev ? *a.nq_dev : a.nq;
     const bool lat = nq <= gridDim.x;
     for (;;) {
