@@ -348,7 +348,7 @@ def main():
         return
 
     import cphnsw_mi355x
-    from cphnsw_mi355x.dist import gather_results
+    from cphnsw_mi355x.dist import PackedResults
 
     cfg = CONFIGS[args.config]
     n = args.n_index or cfg["n"]
@@ -385,8 +385,9 @@ def main():
     del X
 
     streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    outs = [(torch.empty((nq_gpu, k_run), dtype=torch.int64, device=dev),
-             torch.empty((nq_gpu, k_run), dtype=torch.float32, device=dev)) for _ in range(2)]
+    # ids and distances of a step share one byte buffer, so the N > 1 gather is one collective per step
+    packs = [PackedResults(nq_gpu, k_run, world, dev) for _ in range(2)]
+    outs = [(p.ids, p.dist) for p in packs]
 
     def step(i, serial):
         # The path shards by query with no exchange step inside the search; with N > 1 the step ends
@@ -395,7 +396,7 @@ def main():
         ids, d = index.search_batch_device(q_shard, k_run, out=outs[0 if serial else (i & 1)], stream=st)
         if use_dist:
             with torch.cuda.stream(st):
-                gather_results(ids, d, world, force=True)
+                packs[0 if serial else (i & 1)].gather_raw()
         return ids, d
 
     def timed(steps, serial):

@@ -29,6 +29,36 @@ def gather_results(ids, dist_t, world, group=None, force=False):
     return out_ids, out_d
 
 
+class PackedResults:
+    """One rank's (nq, k) result block as a single byte buffer -- ids (int64) first, distances (float32) behind
+    them -- so that the gather is ONE collective of 12*k*nq bytes per rank instead of two.  `ids` and `dist` are views
+    into the buffer (pass them as `out=` of `search_batch_device`); `gather()` all-gathers the buffer into a
+    preallocated (world, bytes) tensor on the current stream and returns the batch's ids and distances."""
+
+    def __init__(self, nq, k, world, device):
+        import torch
+        self.nq, self.k, self.world = nq, k, world
+        self.buf = torch.empty(nq * k * 12, dtype=torch.uint8, device=device)
+        self.ids = self.buf[: nq * k * 8].view(torch.int64).view(nq, k)
+        self.dist = self.buf[nq * k * 8:].view(torch.float32).view(nq, k)
+        self.all = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=device)
+
+    def gather_raw(self, group=None):
+        """The collective alone (what a serving loop enqueues per batch): every rank's buffer into `self.all`."""
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.all.view(-1), self.buf, group=group)
+        return self.all
+
+    def gather(self, group=None):
+        """gather_raw + the (world*nq, k) ids / distances of the whole batch, rank-major."""
+        import torch
+        self.gather_raw(group)
+        nq, k = self.nq, self.k
+        ids = self.all[:, : nq * k * 8].contiguous().view(torch.int64).view(self.world * nq, k)
+        d = self.all[:, nq * k * 8:].contiguous().view(torch.float32).view(self.world * nq, k)
+        return ids, d
+
+
 def search_batch_sharded(search_fn, queries, k, group=None, device=None):
     """Runs `search_fn(shard, k) -> (ids, dist)` (numpy) on this rank's shard of `queries`
     (numpy (n, dim), identical on every rank) and returns the full (n, k) result on every rank.

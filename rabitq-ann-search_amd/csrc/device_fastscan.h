@@ -320,6 +320,56 @@ __device__ __forceinline__ void stage2_est(const QP& q, const LaneEst& v, float 
     }
 }
 
+// The two lower bounds of the N-bit path in ONE instruction stream: the stage-1 bound (stage1_lower above,
+// fastscan_kernel.hpp:403-424) on lanes 0..31 and the stage-2 bound (the `lower` half of est_and_lower,
+// :287-317) on lanes 32..63, for the same neighbour i = lane & 31.  Past their numerators the two are the same
+// sequence of IEEE operations -- (num - ip_cp) / ipq, the affine map (a product commutes), (.. + slack) / sqrt(dqp)
+// (stage 2 divides by max(sqrt(dqp), 1e-10), which IS sqrt(dqp) once dqp >= 1e-12), the clamp to [-1, 1] (equal for
+// every non-NaN value, and none of the operands can be NaN), nop^2 + dqp - c * 2 nop sqrt(dqp) (the sign moves
+// between the factors of an exact product), max(.., 0), and 0 when ipq <= 1e-10 -- so each half of the wave does one of
+// them and a v_permlane32_swap hands both to both halves: two IEEE divisions and a dozen other instructions less per
+// block than evaluating them one after the other on 64 lanes.  (Zero results may differ in sign from the two
+// originals -- `lo < 0 ? 0 : lo` against max(lo, 0) -- which no comparison downstream can see; the block hook
+// and the streaming kernels, whose outputs are compared bit for bit, keep the separate functions.)
+// Requires dqp >= kEpsSmall (the caller tests that wave-uniform fact).
+template <int BW>
+__device__ __forceinline__ void lower_bounds_split(const QP& q, const LaneEst& v, float dqp, float sqrt_dqp,
+                                                   int lane, float& lo_stage1, float& lo_stage2) {
+    static_assert(BW >= 2, "N-bit path");
+    const float invk = 1.0f / 3.0f;
+    const float n1 = __fmaf_rn(q.B * invk, (float)v.pop, (q.A * invk) * (float)v.msb2) + q.C;
+    const float n2 = __fmaf_rn(q.A, (float)v.msb, __fmaf_rn(q.B, (float)v.pop, q.C));
+    const float num = lane >= 32 ? n2 : n1;
+    const float ipq = (v.ip_qo < q.floor) ? q.floor : v.ip_qo;
+    float e = (num - v.ip_cp) / ipq;
+    e = __fmaf_rn(e, q.affine_a, q.affine_b);
+    float c = (e + q.slack) / sqrt_dqp;
+    c = (c < -1.0f) ? -1.0f : ((1.0f < c) ? 1.0f : c);
+    float lo = __fmaf_rn(-c, (v.nop + v.nop) * sqrt_dqp, __fmaf_rn(v.nop, v.nop, dqp));
+    lo = (lo < 0.0f) ? 0.0f : lo;
+    lo = (ipq > kEpsMedium) ? lo : 0.0f;
+    uint32_t a, b;
+    half_pair(__float_as_uint(lo), a, b);
+    lo_stage1 = __uint_as_float(a);
+    lo_stage2 = __uint_as_float(b);
+}
+
+// The estimate half of stage2_est / est_and_lower (BW >= 2), for callers that took the bounds from lower_bounds_split.
+template <int BW>
+__device__ __forceinline__ float stage2_est_only(const QP& q, const LaneEst& v, float dqp) {
+    static_assert(BW >= 2, "N-bit path");
+    if (dqp < kEpsSmall) return __fmaf_rn(v.nop, v.nop, dqp);
+    constexpr float K = (float)((1u << BW) - 1);
+    constexpr float invK = 1.0f / K;
+    const float ipn = __fmaf_rn(q.A * invK, (float)v.nbit, __fmaf_rn(q.B * invK, (float)v.wpop, q.C));
+    const float ipq = vmaxf(v.ip_qo, q.floor);
+    float e = (ipq > kEpsMedium) ? (ipn - v.ip_cp) / ipq : 0.0f;
+    e = __fmaf_rn(q.affine_a, e, q.affine_b);
+    float dist = __fmaf_rn(v.nop, v.nop, dqp);
+    dist = __fmaf_rn(-(2.0f * v.nop), e, dist);
+    return vmaxf(dist, 0.0f);
+}
+
 // ---- exact arithmetic: core/memory.hpp:65-95 -----------------------------------------
 // 8 FMA chains (chain j = elements j, j+8, ...) on the 8 lanes of a lane group, then
 // ((c0+c4)+(c1+c5)) + ((c2+c6)+(c3+c7)) via xor-4, xor-1, xor-2 exchanges (fp add is

@@ -711,10 +711,14 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
             if constexpr (BW == 1) {
                 stage2_est<1>(qp, v, dqp, sq, est, lower);
             } else {
-                float lo1 = stage1_lower<BW>(qp, v, dqp, sq);
+                // both lower bounds at once, one per lane half (see lower_bounds_split); dqp is the popped vertex's
+                // distance, the same in every lane
+                float lo1 = 0.0f, lo2 = 0.0f;
+                if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2);
                 bool surv = (nn_sz < k) || (valid && lo1 < worst0);
                 if (__any(surv)) {
-                    stage2_est<BW>(qp, v, dqp, sq, est, lower);
+                    est = stage2_est_only<BW>(qp, v, dqp);
+                    lower = lo2;
                 } else {
                     est = FMAX;
                     lower = lo1;

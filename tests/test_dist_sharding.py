@@ -66,6 +66,46 @@ def test_two_rank_sharding_matches_single_process(gold, nq):
         assert d.tobytes() == want_d.tobytes()
 
 
+def _packed_worker(rank, world, port, nq, k, q):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+    import torch
+    import torch.distributed as dist
+    from golden_util import golden
+    from cphnsw_mi355x.dist import PackedResults
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = golden()
+        pk = PackedResults(nq, k, world, torch.device("cpu"))
+        # each rank fills its views with its shard of the golden result, as search_batch_device(out=...) would
+        pk.ids.copy_(torch.from_numpy(g["S/g128/b4/plain/k10/ids"][rank * nq:(rank + 1) * nq]))
+        pk.dist.copy_(torch.from_numpy(g["S/g128/b4/plain/k10/d"][rank * nq:(rank + 1) * nq]))
+        ids, d = pk.gather()
+        q.put((rank, ids.numpy(), d.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_gather_is_one_collective_and_rank_major(gold):
+    """PackedResults (bench.py's N > 1 step): ids and distances travel in one byte buffer per rank."""
+    world, k, nq = 2, 10, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, nq, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, ids, d in res:
+        assert np.array_equal(ids, gold["S/g128/b4/plain/k10/ids"][:world * nq])
+        assert d.tobytes() == gold["S/g128/b4/plain/k10/d"][:world * nq].tobytes()
+
+
 def test_shard_bounds_cover_everything():
     from cphnsw_mi355x.dist import shard_bounds
     for n in (0, 1, 7, 8, 10_000, 10_001):
@@ -85,7 +125,7 @@ def _gpu_worker(port, q):
     import torch.distributed as dist
     from golden_util import fixture_path, golden
     import cphnsw_mi355x
-    from cphnsw_mi355x.dist import gather_results, search_batch_sharded
+    from cphnsw_mi355x.dist import PackedResults, gather_results, search_batch_sharded
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -105,7 +145,13 @@ def _gpu_worker(port, q):
         with torch.cuda.stream(st):
             gi, gd = gather_results(di, dd, 1, force=True)
         st.synchronize()
-        q.put((ids, d, gi.cpu().numpy(), gd.cpu().numpy()))
+        # ... and exactly bench.py's step: results written into the packed buffer, one collective behind the search
+        pk = PackedResults(len(Q), 10, 1, dev)
+        ix.search_batch_device(qd, 10, out=(pk.ids, pk.dist), stream=st)
+        with torch.cuda.stream(st):
+            pi, pd = pk.gather()
+        st.synchronize()
+        q.put((ids, d, gi.cpu().numpy(), gd.cpu().numpy(), pi.cpu().numpy(), pd.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -118,9 +164,9 @@ def test_rccl_gather_of_hip_search_matches_goldens(gold):
     q = ctx.Queue()
     p = ctx.Process(target=_gpu_worker, args=(_free_port(), q))
     p.start()
-    ids, d, gi, gd = q.get(timeout=300)
+    ids, d, gi, gd, pi, pd = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
-    for a, b in ((ids, d), (gi, gd)):
+    for a, b in ((ids, d), (gi, gd), (pi, pd)):
         assert np.array_equal(a, gold["S/g128/b4/plain/k10/ids"])
         assert b.tobytes() == gold["S/g128/b4/plain/k10/d"].tobytes()
