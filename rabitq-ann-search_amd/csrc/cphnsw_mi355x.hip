@@ -318,13 +318,12 @@ BatchSet& next_set(cph_index* h, hipStream_t st) {
         HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.pin_stats), kStatWords * 8, hipHostMallocDefault));
         std::memset(s.pin_stats, 0, kStatWords * 8);
     }
-    if (s.used) {
-        if (hipEventQuery(s.ev_done) == hipSuccess) {
-            if (s.pin_stats[5] != 0 && s.cap < h->host.n + 1)
-                h->auto_cap = std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(h->host.n + 1, s.cap * 4));
-        }
-        HIP_CHECK(hipStreamWaitEvent(st, s.ev_done, 0));
+    // (either set's finished batch counts: the other set's is the more recent one)
+    for (BatchSet& o : h->sets) {
+        if (o.used && o.ev_done && hipEventQuery(o.ev_done) == hipSuccess && o.pin_stats[5] != 0 && o.cap < h->host.n + 1)
+            h->auto_cap = std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(h->host.n + 1, o.cap * 4));
     }
+    if (s.used) HIP_CHECK(hipStreamWaitEvent(st, s.ev_done, 0));
     return s;
 }
 

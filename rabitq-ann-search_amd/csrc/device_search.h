@@ -164,6 +164,11 @@ struct Beam {
     __device__ __forceinline__ void put(uint32_t i, uint4 v) const {
         if (i < kBeamLds) lds_put(i, v); else g[i] = v;
     }
+    __device__ __forceinline__ float raw_key(uint32_t i) const {
+        float k;
+        if (i < kBeamLds) k = lds_key(i); else k = reinterpret_cast<const float*>(g)[4 * (size_t)i];
+        return k;
+    }
     __device__ __forceinline__ BeamEntry get(uint32_t i) const {
         const uint4 v = raw(i);
         return BeamEntry{__uint_as_float(v.x), __uint_as_float(v.y), v.z};
@@ -196,36 +201,6 @@ constexpr uint32_t kWaveHeapMax = 256;   // largest heap the wave-parallel pop h
 
 __device__ __forceinline__ uint4 beam_pack(const BeamEntry& e) {
     return make_uint4(__float_as_uint(e.est), __float_as_uint(e.lower), e.id, 0u);
-}
-
-__device__ __forceinline__ void beam_sift_up(const Beam& h, uint32_t hole, uint32_t top, uint4 v) {
-    const float vk = __uint_as_float(v.x);
-    while (hole > top) {
-        const uint32_t p = (hole - 1) >> 1;
-        const uint4 pv = h.raw(p);
-        if (!(__uint_as_float(pv.x) > vk)) break;
-        h.put(hole, pv);
-        hole = p;
-    }
-    h.put(hole, v);
-}
-__device__ __forceinline__ void beam_adjust(const Beam& h, uint32_t hole, uint32_t len, uint4 v) {
-    const uint32_t top = hole;
-    uint32_t child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        uint4 r = h.raw(child);
-        const uint4 lft = h.raw(child - 1);
-        if (__uint_as_float(r.x) > __uint_as_float(lft.x)) { --child; r = lft; }
-        h.put(hole, r);
-        hole = child;
-    }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        h.put(hole, h.raw(child - 1));
-        hole = child - 1;
-    }
-    beam_sift_up(h, hole, top, v);
 }
 
 // std::pop_heap of a beam that lives entirely in LDS (size <= kBeamLds), executed by the whole
@@ -330,6 +305,100 @@ __device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typena
     const uint32_t m = (uint32_t)__builtin_ctzll(stop);                 // ancestors p_1..p_m move down
     if (t <= m) h.lds_put((hp >> (t - 1)) - 1, e);                      // p_t's entry to p_(t-1), p_0 = the leaf
     if ((uint32_t)lane == m) h.lds_put((hp >> m) - 1, v);              // (m <= depth <= 8 < 64: that lane exists)
+}
+
+// ---- the same two operations for a beam that has outgrown its LDS levels (entries kBeamLds.. live in HBM) --------
+// A lane-0 sift is one dependent HBM round trip per heap level below the LDS part -- 5 to 10 of them per pop once a beam
+// holds thousands of entries (the recall >= 0.95 workload: 63 % of the kernel's time went there).  The moves stay
+// libstdc++'s; the schedule becomes: (1) the 7 LDS levels are walked on ballot masks as in heap_pop_wave; (2) below them
+// the wave reads a WINDOW of the subtree under the current node -- its 62 descendants of the next five levels, one key
+// per lane, one round trip -- decides every "which child moves up" of the window with one ballot and walks five levels
+// on the mask; (3) the path is then a bit string, so every lane knows its pair of positions and the entries move with
+// one parallel read (lines the window just brought into L2) and one parallel write.  Two to four round trips in
+// place of one per level: 334 -> 216 ms per 10,000 queries of that workload.  (Also tried: six-level windows holding
+// whole entries, two per lane, with the path's lanes storing their entries one level up and no re-read -- one round
+// trip per pop, but 12 more live registers where the block's loads are in flight: spills, 251 ms there and the
+// D = 128 / 4-bit kernel 12 % slower.)
+__device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, int lane) {
+    const uint32_t len = size - 1;                 // >= kBeamLds: the last element lives in HBM
+    const uint4 v = h.g[len];                      // the value __adjust_heap re-inserts (same address in every lane)
+    // LDS levels 0..6: nodes 0..126, both children always inside the LDS part
+    const bool b0 = Beam::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1));
+    const unsigned long long m0 = __ballot(b0);
+    bool b1 = false;
+    if (lane < 63) b1 = Beam::before(h.lds_key(2 * lane + 130), h.lds_key(2 * lane + 129));
+    const unsigned long long m1 = __ballot(b1);
+    uint32_t hp = 1, d = 7;                        // hp = hole + 1, the path as a bit string (see heap_pop_wave)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const uint32_t hole = hp - 1;
+        const unsigned long long m = hole < 64 ? m0 : m1;
+        hp = 2 * hp + 1 - ((uint32_t)(m >> (hole & 63)) & 1u);
+    }
+    // HBM levels: windows of five levels under node hp - 1
+    const float* gk = reinterpret_cast<const float*>(h.g);
+    for (;;) {
+        if (2 * hp >= len) break;                  // no right child: __adjust_heap's loop ends here
+        const uint32_t r = (uint32_t)lane + 2;     // relative node, 1-based, root = 1: lanes 0..61 hold 2..63
+        const uint32_t dr = 31u - (uint32_t)__builtin_clz(r);
+        const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
+        float key = 0.0f;
+        if (lane < 62 && idx < len) key = gk[4 * (size_t)idx];
+        const float key_r = __shfl_down(key, 1);   // even lanes hold left children, their right siblings sit one lane up
+        const bool both = (lane & 1) == 0 && lane < 62 && idx + 1 < len;
+        const unsigned long long E2 = __ballot(both);
+        const unsigned long long M = __ballot(both && Beam::before(key_r, key));   // true: the left child moves up
+        uint32_t P = 1, steps = 0;
+        while (steps < 5) {
+            const uint32_t bit = 2 * P - 2;        // the pair under relative node P sits in lanes 2P-2, 2P-1
+            if (!((E2 >> bit) & 1ull)) break;
+            P = 2 * P + 1 - ((uint32_t)(M >> bit) & 1u);
+            ++steps;
+        }
+        hp = (hp << steps) | (P & ((1u << steps) - 1u));
+        d += steps;
+        if (steps < 5) break;
+    }
+    if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
+        hp = 2 * hp;
+        ++d;
+    }
+    // the moves (heap_pop_wave's second half on the hybrid accessors; d <= 31 lanes take part)
+    const uint32_t hole = hp - 1;
+    const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
+    const uint32_t my_dst = (hp >> (d - t)) - 1;
+    const uint32_t my_src = (hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u))) - 1;
+    uint4 e = v;
+    bool c = false;
+    if ((uint32_t)lane < d) {
+        e = h.raw(my_src);
+        c = Beam::before(Beam::key_of(e), Beam::key_of(v));
+    }
+    const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
+    const uint32_t fin = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;
+    if ((uint32_t)lane < fin) h.put(my_dst, e);
+    if (fin == d) { if (lane == 0) h.put(hole, v); }
+    else if ((uint32_t)lane == fin) h.put(my_dst, v);
+}
+
+// std::push_heap of `v` at index `hole` >= kBeamLds: heap_push_wave on the hybrid accessors -- the ancestors of the
+// leaf (LDS or HBM, by index) are read by one lane each, one round trip whatever the depth.
+__device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, uint4 v, int lane) {
+    const uint32_t hp = hole + 1;
+    const uint32_t depth = 31u - (uint32_t)__builtin_clz(hp);
+    const uint32_t t = (uint32_t)lane + 1;
+    const bool on = t <= depth;
+    const uint32_t pt = on ? (hp >> t) - 1 : 0u;
+    uint4 e = v;
+    bool down = false;
+    if (on) {
+        e = h.raw(pt);
+        down = Beam::before(Beam::key_of(e), Beam::key_of(v));
+    }
+    const unsigned long long stop = ~__ballot(down);
+    const uint32_t m = (uint32_t)__builtin_ctzll(stop);
+    if (t <= m) h.put((hp >> (t - 1)) - 1, e);
+    if ((uint32_t)lane == m) h.put((hp >> m) - 1, v);
 }
 
 // BoundedMaxHeap::push (rabitq_search.hpp:26-35) by the whole wave; every argument is wave-uniform, `top` is the
@@ -542,12 +611,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
             // std::pop_heap of the beam (whole wave while it lives in LDS, lane 0 once it has spilled)
             auto pop_beam = [&](uint32_t size) {
                 if (size > 1) {
-                    if (size <= kBeamLds) {
-                        heap_pop_wave(heap, size, lane);
-                    } else {
-                        if (lane == 0) beam_adjust(heap, 0, size - 1, heap.raw(size - 1));
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    if (size <= kBeamLds) heap_pop_wave(heap, size, lane);
+                    else beam_pop_hybrid(heap, size, lane);
                 }
             };
             {
@@ -777,12 +842,14 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
                 // are independent appends -- each lane checks its own parent and writes its own leaf.
                 const uint32_t np = __popc(pm);
                 bool appended = false;
-                if (np != 0 && np <= beam_size + 1 && beam_size + np <= kBeamLds) {
+                if (np != 0 && np <= beam_size + 1) {
                     const uint32_t pos = beam_size + __builtin_amdgcn_mbcnt_lo(pm, 0u);
+                    const bool in_lds = beam_size + np <= kBeamLds;   // wave-uniform: the usual case keeps its ds_* accesses
                     bool stay = true;
-                    if (p && pos > 0) stay = !(heap.lds_key((pos - 1) >> 1) > est);
+                    if (p && pos > 0) stay = !((in_lds ? heap.lds_key((pos - 1) >> 1) : heap.raw_key((pos - 1) >> 1)) > est);
                     if (__all(stay)) {
-                        if (p) heap.lds_put(pos, make_uint4(__float_as_uint(est), __float_as_uint(lower), nid, 0u));
+                        const uint4 ent = make_uint4(__float_as_uint(est), __float_as_uint(lower), nid, 0u);
+                        if (p) { if (in_lds) heap.lds_put(pos, ent); else heap.put(pos, ent); }
                         beam_size += np;
                         st_push += np;
                         appended = true;
@@ -795,12 +862,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
                         const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
                         const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
                         const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
-                        if (beam_size < kBeamLds) {
-                            heap_push_wave(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
-                        } else {
-                            if (lane == 0) beam_sift_up(heap, beam_size, 0, make_uint4(e_i, lo_i, id_i, 0u));
-                            __builtin_amdgcn_wave_barrier();
-                        }
+                        if (beam_size < kBeamLds) heap_push_wave(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
+                        else beam_push_hybrid(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
                         ++beam_size;
                         ++st_push;
                     }
@@ -857,12 +920,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
                     }
                     if (bcast_u32(push ? 1u : 0u)) {
                         const uint4 ent = beam_pack(BeamEntry{key, lo, id_i});
-                        if (beam_size < kBeamLds) {
-                            heap_push_wave(heap, beam_size, ent, lane);
-                        } else {
-                            if (lane == 0) beam_sift_up(heap, beam_size, 0, ent);
-                            __builtin_amdgcn_wave_barrier();
-                        }
+                        if (beam_size < kBeamLds) heap_push_wave(heap, beam_size, ent, lane);
+                        else beam_push_hybrid(heap, beam_size, ent, lane);
                         ++beam_size;
                         ++st_push;
                     }

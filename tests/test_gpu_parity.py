@@ -253,6 +253,37 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+def test_beams_beyond_the_lds_levels_match_oracle(cph, oracle, tmp_path):
+    """Gaussian data at low bit width: thousands of expansions per query, beams of thousands of entries -- the
+    heap levels past the 255 LDS entries live in HBM and are popped / pushed by the window routines
+    (beam_pop_hybrid, beam_push_hybrid).  Index built by this repo's builder; ids and distance bits against the oracle
+    (and the compiled reference when it is on the box), in throughput mode and in latency mode (batch <= slots)."""
+    from oracle_lib import Oracle, ref_available, ref_module
+    rng = np.random.default_rng(2024)
+    n, dim, bits, k = 30000, 64, 2, 20
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((96, dim)).astype(np.float32)
+    ix = cph.CPIndex(dim, bits)
+    ix.build(X)
+    ix.finalize()
+    p = str(tmp_path / "spill.idx")
+    ix.save(p)
+    oids, od, _ = Oracle().load(p).search_batch(Q, k)
+    ids, d = ix.search_batch(Q, k)
+    st = ix.last_search_stats()
+    assert st["expansions"] / len(Q) > 1500, st          # the regime the test is about
+    assert st["beam_pushes"] / len(Q) > 2000, st
+    assert np.array_equal(ids, oids) and _beq(d, od)
+    ix.set_search_params(slots=64, beam_capacity=0)       # 96 queries on 64 slots: a queue, no latency mode
+    ids2, d2 = ix.search_batch(Q, k)
+    assert np.array_equal(ids2, oids) and _beq(d2, od)
+    if ref_available():
+        r = ref_module().CPIndex(dim, bits)
+        r.load(p)
+        rids, rd = r.search_batch(Q, k)
+        assert np.array_equal(ids, rids) and _beq(d, rd)
+
+
 @pytest.mark.parametrize("name,bits", [("g128", 4), ("g16", 2)])
 def test_repeated_neighbour_ids(cph, oracle, gold, tmp_path, name, bits):
     """A graph whose neighbour lists repeat an id (the reference never writes one, the loader flags
