@@ -181,53 +181,90 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
         if (delta < ceps) delta = ceps;
         const float inv_delta = 1.0f / delta;
         float dot = 0.0f, nrm = 0.0f;
-        for (uint32_t i = 0; i < D; ++i) {
-            const float v = x[i];
-            int q = (int)__fmaf_rn(v - mn, inv_delta, 0.5f);
-            q = q < 0 ? 0 : (q > Ki ? Ki : q);
-            u[i] = (uint8_t)q;
-            const float c = ctab[q];
-            dot = dot + c * v;
-            nrm = nrm + c * c;
+        for (uint32_t i0 = 0; i0 < D; i0 += 4) {     // four coordinates' reads together, sums in order
+            float xv[4], c[4];
+            uint32_t un = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = x[i0 + j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int q = (int)__fmaf_rn(xv[j] - mn, inv_delta, 0.5f);
+                q = q < 0 ? 0 : (q > Ki ? Ki : q);
+                un |= (uint32_t)q << (8 * j);
+                c[j] = ctab[q];
+            }
+            *reinterpret_cast<uint32_t*>(u + i0) = un;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dot = dot + c[j] * xv[j];
+                nrm = nrm + c[j] * c[j];
+            }
+        }
+        // The descent is sequential in i (each coordinate sees the running dot / norm of all earlier ones), but what it
+        // READS is not: four coordinates' values, their codes (one dword) and the levels around each code are fetched
+        // together before the four dependent updates -- two LDS round trips per four coordinates instead of two per
+        // coordinate (the loop is latency-bound: 8 to 32 lanes of the wave are live).  D is a multiple of 16.
+        float ct[BW >= 4 ? 1 : Ki + 1];                 // 2-bit: all four levels in registers
+        if constexpr (BW < 4) {
+#pragma unroll
+            for (int t = 0; t <= Ki; ++t) ct[t] = ctab[t];
         }
         float prev = 0.0f;
         for (int iter = 0; iter < 10; ++iter) {
             bool changed = false;
-            for (uint32_t i = 0; i < D; ++i) {
-                const float v = x[i];
-                const int ou = u[i];
-                const float oc = ctab[ou];
-                const float dwo = __fmaf_rn(-oc, v, dot);
-                const float nwo = __fmaf_rn(-oc, oc, nrm);
-                int bu = ou;
-                float bd = dot, bn = nrm;
-                if constexpr (BW >= 4) {
-                    if (ou - 1 >= 0) {
-                        const float c = ctab[ou - 1];
-                        const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
-                        if (nd * nd * bn > bd * bd * nn) { bu = ou - 1; bd = nd; bn = nn; }
-                    }
-                    if (ou + 1 <= Ki) {
-                        const float c = ctab[ou + 1];
-                        const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
-                        if (nd * nd * bn > bd * bd * nn) { bu = ou + 1; bd = nd; bn = nn; }
-                    }
-                } else {
+            for (uint32_t i0 = 0; i0 < D; i0 += 4) {
+                const uint32_t up = *reinterpret_cast<const uint32_t*>(u + i0);
+                float xv[4], oc[4], cl[4], ch[4];
 #pragma unroll
-                    for (int t = 0; t <= Ki; ++t) {
-                        if (t == ou) continue;
-                        const float c = ctab[t];
-                        const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
-                        if (nd * nd * bn > bd * bd * nn) { bu = t; bd = nd; bn = nn; }
+                for (int j = 0; j < 4; ++j) xv[j] = x[i0 + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ou = (int)((up >> (8 * j)) & 255u);
+                    oc[j] = ctab[ou];
+                    if constexpr (BW >= 4) {
+                        cl[j] = ctab[ou > 0 ? ou - 1 : 0];
+                        ch[j] = ctab[ou < Ki ? ou + 1 : Ki];
                     }
                 }
-                if (bu != ou) {
-                    const float nc = ctab[bu];
-                    dot = __fmaf_rn(nc, v, dwo);
-                    nrm = __fmaf_rn(nc, nc, nwo);
-                    u[i] = (uint8_t)bu;
-                    changed = true;
+                uint32_t un = up;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = xv[j];
+                    const int ou = (int)((up >> (8 * j)) & 255u);
+                    const float dwo = __fmaf_rn(-oc[j], v, dot);
+                    const float nwo = __fmaf_rn(-oc[j], oc[j], nrm);
+                    int bu = ou;
+                    float bd = dot, bn = nrm;
+                    if constexpr (BW >= 4) {
+                        if (ou - 1 >= 0) {
+                            const float c = cl[j];
+                            const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
+                            if (nd * nd * bn > bd * bd * nn) { bu = ou - 1; bd = nd; bn = nn; }
+                        }
+                        if (ou + 1 <= Ki) {
+                            const float c = ch[j];
+                            const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
+                            if (nd * nd * bn > bd * bd * nn) { bu = ou + 1; bd = nd; bn = nn; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t <= Ki; ++t) {
+                            if (t == ou) continue;
+                            const float c = ct[t];
+                            const float nd = __fmaf_rn(c, v, dwo), nn = __fmaf_rn(c, c, nwo);
+                            if (nd * nd * bn > bd * bd * nn) { bu = t; bd = nd; bn = nn; }
+                        }
+                    }
+                    if (bu != ou) {
+                        // (the new level is one of the three just tried: its running sums are bd / bn, computed by the same
+                        // two fused operations the reference repeats for the winner)
+                        dot = bd;
+                        nrm = bn;
+                        un = (un & ~(255u << (8 * j))) | ((uint32_t)bu << (8 * j));
+                        changed = true;
+                    }
                 }
+                if (un != up) *reinterpret_cast<uint32_t*>(u + i0) = un;
             }
             if (!changed) break;
             const float cs = nrm > 0.0f ? dot * dot / nrm : 0.0f;
@@ -236,13 +273,23 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
         }
         float ipqo = 0.0f, ipcp = 0.0f;
         uint32_t msb = 0, wp = 0;
-        for (uint32_t i = 0; i < D; ++i) {
-            const int q = u[i];
-            const float c = ctab[q];
-            ipqo = __fmaf_rn(c, x[i], ipqo);
-            if (rp) ipcp = __fmaf_rn(c, rp[i], ipcp);
-            wp += (uint32_t)q;
-            msb += (uint32_t)((q >> (BW - 1)) & 1);
+        for (uint32_t i0 = 0; i0 < D; i0 += 4) {
+            const uint32_t up = *reinterpret_cast<const uint32_t*>(u + i0);
+            float xv[4], rv[4], c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xv[j] = x[i0 + j];
+                rv[j] = rp ? rp[i0 + j] : 0.0f;
+                c[j] = ctab[(up >> (8 * j)) & 255u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = (up >> (8 * j)) & 255u;
+                ipqo = __fmaf_rn(c[j], xv[j], ipqo);
+                if (rp) ipcp = __fmaf_rn(c[j], rv[j], ipcp);
+                wp += q;
+                msb += (q >> (BW - 1)) & 1u;
+            }
         }
         o.ip_qo = ipqo * inv_sqrt_d;
         o.ip_cp = ipcp * inv_sqrt_d;
