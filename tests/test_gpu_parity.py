@@ -253,6 +253,18 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+@pytest.mark.parametrize("k", [256, 257, 300, 1000])
+def test_large_k_result_heap(cph, gold, k):
+    """k past the 256 entries the wave-parallel result-heap routines cover (kWaveHeapMax): the heap falls back to the
+    lane-0 sift; k = 1000 also exceeds what the small fixture can return (padding with -1 / FLT_MAX)."""
+    from oracle_lib import Oracle
+    ix = _load(cph, "g128", 4)
+    Q = gold["Q/g128"][:16]
+    oids, od, _ = Oracle().load(fixture_path("g128", 4)).search_batch(Q, k)
+    ids, d = ix.search_batch(Q, k)
+    assert np.array_equal(ids, oids) and _beq(d, od)
+
+
 def test_beams_beyond_the_lds_levels_match_oracle(cph, oracle, tmp_path):
     """Gaussian data at low bit width: thousands of expansions per query, beams of thousands of entries -- the
     heap levels past the 255 LDS entries live in HBM and are popped / pushed by the window routines
