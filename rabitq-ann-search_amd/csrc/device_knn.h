@@ -30,6 +30,13 @@
 // consecutive MFMAs; A and B use the same k for the same (lane half, step), which is all the
 // instruction needs -- the order in which k is summed is irrelevant to an exact-kNN list.  The 36-float
 // stride makes the 16 rows of each ds_read_b128 lane group land on 16 distinct 4-bank spans.
+//
+// Where the time goes (stamps per phase, 262,144 x 128): MFMA issue 48 %, the tile epilogue (filter) 18 %, and per
+// 32-float chunk about 2,000 cycles of operand reads, staging and barrier that one wave per SIMD cannot hide behind
+// its own 4,100 cycles of MFMAs.  A three-stage software pipeline (operands of chunk g+1 read from LDS during chunk g's
+// MFMAs, global prefetch two chunks deeper, sched_group_barrier interleave) was built and measured: the second operand
+// set does not fit next to accumulators, prefetch and thresholds in 256 architectural registers, the compiler parks
+// it in AGPRs and moves it back and forth (hundreds of v_accvgpr moves per chunk): 70 TF/s against 82.  Reverted.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
     __shared__ uint32_t ci[kKnnTile * kKnnCap];
     __shared__ uint32_t cnt[kKnnTile];
     __shared__ float sig[kKnnTile];
+    __shared__ float bn_s[2][kKnnTile];                          // accumulator start values of the tile's columns (by tile parity)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -115,8 +123,13 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         qsrc[i] = a.q + (size_t)(qr < a.nq ? qr : a.nq - 1) * D + skq;
     }
     knn_f32x4 pq[4], pb[4];
+    float pbn = 0.0f;                   // -|b|^2 / 2 of column tid of the tile being fetched (chunk 0 only)
     auto fetch = [&](uint32_t tile, uint32_t ch) {
         const uint32_t k0 = ch * kKnnKC;
+        if (ch == 0 && tid < kKnnTile) {
+            const uint32_t col = tile * kKnnTile + tid;
+            pbn = col < a.nb ? -0.5f * a.bnorm[col] : NEG_INF;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t br = tile * kKnnTile + srow + 32 * i;
@@ -124,7 +137,8 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
             pb[i] = *reinterpret_cast<const knn_f32x4*>(a.b + (size_t)(br < a.nb ? br : a.nb - 1) * D + skq + k0);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, bool first_chunk, uint32_t tile) {
+        if (first_chunk && tid < kKnnTile) bn_s[tile & 1][tid] = pbn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<knn_f32x4*>(&Qs[buf][(srow + 32 * i) * kKnnLd + skq]) = pq[i];
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
     const int wrow = wave * 32;         // first tile row of this wave
 
     fetch(0, 0);
-    stage(0);
+    stage(0, true, 0);
     __syncthreads();                    // first operand image, cnt and sig are in place
     int buf = 0;
     for (uint32_t tile = 0; tile < ntile; ++tile)
@@ -147,8 +161,9 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         if (ch == 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const uint32_t col = tile * kKnnTile + t * 32 + c;
-                const float init = col < a.nb ? -0.5f * a.bnorm[col] : NEG_INF;
+                // (staged through LDS with the tile's first operand image: a global load here would be a full memory
+                // round trip in front of every tile with nothing to overlap it -- it was a third of the kernel's time)
+                const float init = bn_s[tile & 1][t * 32 + c];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = init;
             }
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         }
         // The other image was last read one chunk ago and every wave has passed a barrier since: it can
         // be overwritten now; ONE barrier per chunk then publishes it.
-        stage(buf ^ 1);
+        stage(buf ^ 1, wrap, tile + 1);
         __syncthreads();
         buf ^= 1;
         if (ch + 1 != nchunk) continue;
