@@ -21,6 +21,7 @@
 //  * the kernel is instruction-issue bound: there is no software prefetch, the
 //    probe is a load (atomics only for new ids), shuffles are DPP / v_permlane32_swap.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include "cph_core.h"
@@ -68,6 +69,20 @@ struct SearchArgs {
     uint32_t* redo;         // [nq] or null
     uint32_t* redo_count;
 };
+
+// Kernel arguments that are touched once per query (work queue, encoded-query arrays, outputs, statistics) are read from
+// the kernarg segment where they are used instead of living in scalar registers across the expansion loop: the
+// pointer is laundered through an empty asm so that the loads cannot be hoisted.  (With every argument resident the
+// allocator spilled ~50 SGPRs to VGPR lanes -- 133 v_readlane reloads in the <4,128> instantiation; now 19 and 27.
+// The reloads were mostly off the expansion loop's usual path: the kernel time did not change measurably.)
+template <class T>
+__device__ __forceinline__ T cold_arg(size_t offset) {
+    typedef __attribute__((address_space(4))) const unsigned char kbyte;
+    kbyte* p = (kbyte*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(__attribute__((address_space(4))) const T*)(p + offset);
+}
+#define CPH_COLD(field) cold_arg<decltype(SearchArgs::field)>(offsetof(SearchArgs, field))
 
 // ---- libstdc++-compatible binary heaps ------------------------------------------------
 // Result heap: max-heap on dist (std::less via SearchResult::operator<, core/types.hpp:16).
@@ -515,11 +530,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     const uint32_t vec_off = __builtin_amdgcn_groupstaticsize() + PW * 16 + D * 4;
     const uint32_t pf_off = vec_off + vsz;
     const uint32_t slot = blockIdx.x;
-    uint32_t* bm = a.bitmaps + (size_t)slot * a.bm_words;
-    uint32_t* logi = a.log_ids + (size_t)slot * a.cap;
+    uint32_t* bm = CPH_COLD(bitmaps) + (size_t)slot * CPH_COLD(bm_words);
+    uint32_t* logi = CPH_COLD(log_ids) + (size_t)slot * a.cap;
     Beam heap;
     heap.l = s_beam;
-    heap.g = a.beam + (size_t)slot * a.cap;
+    heap.g = CPH_COLD(beam) + (size_t)slot * a.cap;
     const float FMAX = 3.402823466e+38f;
     if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
@@ -538,18 +553,24 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     // before this expansion's beam pushes (the next top is known without doing them) 2.36 -> 2.46 ms per 10k
     // queries; doing the same at a second issue site made the register allocator copy the loaded registers at the
     // loop head, i.e. wait for them: 2.50 ms.  Fewer instructions per expansion is the only lever left.
-    const uint32_t nq = a.nq_dev ? *a.nq_dev : a.nq;
+    const uint32_t* nq_dev = CPH_COLD(nq_dev);
+    const uint32_t nq = nq_dev ? *nq_dev : CPH_COLD(nq);
     const bool lat = nq <= gridDim.x;
     for (;;) {
         uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(a.counter, 1u);
+        if (lane == 0) t = atomicAdd(CPH_COLD(counter), 1u);
         t = bcast_u32(t);
         if (t >= nq) break;
-        const uint32_t qi = a.todo ? a.todo[t] : t;
+        const uint32_t* todo = CPH_COLD(todo);
+        const uint32_t qi = todo ? todo[t] : t;
 
-        for (uint32_t w = lane; w < PW; w += 64) qm[w] = a.qmasks[(size_t)qi * PW + w];
-        for (uint32_t d = lane; d < D; d += 64) qv[d] = a.queries[(size_t)qi * D + d];
-        const QueryHeader hd = a.qhdr[qi];
+        {
+            const uint4* qmasks = CPH_COLD(qmasks);
+            const float* queries = CPH_COLD(queries);
+            for (uint32_t w = lane; w < PW; w += 64) qm[w] = qmasks[(size_t)qi * PW + w];
+            for (uint32_t d = lane; d < D; d += 64) qv[d] = queries[(size_t)qi * D + d];
+        }
+        const QueryHeader hd = CPH_COLD(qhdr)[qi];
         __syncthreads();
 
         QP qp;
@@ -941,38 +962,43 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
         const uint32_t nn_final = bcast_u32(nn_size);
         __syncthreads();
         if (!overflow) {
+            int64_t* out_ids = CPH_COLD(out_ids);
+            float* out_dist = CPH_COLD(out_dist);
             for (uint32_t j = lane; j < k; j += 64) {
                 if (j < nn_final) {
-                    a.out_ids[(size_t)qi * k + j] = (int64_t)nn[j].id;
-                    a.out_dist[(size_t)qi * k + j] = nn[j].dist;
+                    out_ids[(size_t)qi * k + j] = (int64_t)nn[j].id;
+                    out_dist[(size_t)qi * k + j] = nn[j].dist;
                 } else {
-                    a.out_ids[(size_t)qi * k + j] = -1;
-                    a.out_dist[(size_t)qi * k + j] = FMAX;
+                    out_ids[(size_t)qi * k + j] = -1;
+                    out_dist[(size_t)qi * k + j] = FMAX;
                 }
             }
         }
         if (lane == 0) {
-            a.out_count[qi] = nn_final;
+            CPH_COLD(out_count)[qi] = nn_final;
             // bits 0..7: QueryStatus; bits 8..31: vertices expanded (per-query work, for load analysis)
-            a.status[qi] = (overflow ? kStatusOverflow : kStatusOk) | (st_exp << 8);
-            atomicAdd(&a.stats[0], (unsigned long long)st_exp);
-            atomicAdd(&a.stats[1], (unsigned long long)st_exact);
-            atomicAdd(&a.stats[2], (unsigned long long)st_new);
-            atomicAdd(&a.stats[3], (unsigned long long)st_push);
-            atomicAdd(&a.stats[4], (unsigned long long)st_skip);
-            atomicAdd(&a.stats[7], (unsigned long long)st_allseen);
+            CPH_COLD(status)[qi] = (overflow ? kStatusOverflow : kStatusOk) | (st_exp << 8);
+            unsigned long long* stats = CPH_COLD(stats);
+            atomicAdd(&stats[0], (unsigned long long)st_exp);
+            atomicAdd(&stats[1], (unsigned long long)st_exact);
+            atomicAdd(&stats[2], (unsigned long long)st_new);
+            atomicAdd(&stats[3], (unsigned long long)st_push);
+            atomicAdd(&stats[4], (unsigned long long)st_skip);
+            atomicAdd(&stats[7], (unsigned long long)st_allseen);
 #ifdef CPH_PHASE_TIMERS
-            for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[8 + i], tph[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tph[i]);
 #endif
             if (overflow) {
-                atomicAdd(&a.stats[5], 1ull);
-                if (a.redo) a.redo[atomicAdd(a.redo_count, 1u)] = qi;
+                atomicAdd(&stats[5], 1ull);
+                uint32_t* redo = CPH_COLD(redo);
+                if (redo) redo[atomicAdd(CPH_COLD(redo_count), 1u)] = qi;
             }
         }
         // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --
         __syncthreads();
         if (overflow) {
-            for (uint64_t w = lane; w < a.bm_words; w += 64) bm[w] = 0u;
+            const uint64_t bm_words = CPH_COLD(bm_words);
+            for (uint64_t w = lane; w < bm_words; w += 64) bm[w] = 0u;
         } else {
             for (uint32_t j = lane; j < log_count; j += 64) bm[logi[j] >> 5] = 0u;
         }
