@@ -1,6 +1,7 @@
 // builder_pipeline.h — finalize(): the construction pipeline of builder.h, stage by stage, and the
 // calibration that follows it.  See builder.h for the design and the reference citations.
 #pragma once
+#include <type_traits>
 #include "builder.h"
 
 namespace cph {
@@ -14,18 +15,47 @@ struct BuiltDevice {            // the searchable index as the pipeline leaves i
 
 inline size_t isqrt_sz(size_t n) { return (size_t)std::floor(std::sqrt((double)n)); }
 
-template <int BW>
+template <int BW, bool G>
 inline void launch_encode(const EncodeArgsB& a, uint32_t grid, size_t lds) {
     if (lds > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_edges_kernel<BW>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_edges_kernel<BW, G>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(encode_edges_kernel<BW>, dim3(grid), dim3(64), lds, nullptr, a);
+    hipLaunchKernelGGL((encode_edges_kernel<BW, G>), dim3(grid), dim3(64), lds, nullptr, a);
     HIP_CHECK(hipGetLastError());
 }
-inline void launch_encode_bits(size_t bw, const EncodeArgsB& a, uint32_t grid, size_t lds) {
-    if (bw == 1) launch_encode<1>(a, grid, lds);
-    else if (bw == 2) launch_encode<2>(a, grid, lds);
-    else launch_encode<4>(a, grid, lds);
+// Edge (a.nbr set) or own-code (a.nbr null) encoding of `units` workgroup units.  Up to D = 256 all 32 edges of a vertex
+// fit the LDS budget of a workgroup; beyond that the rows live in a transposed HBM scratch (device_build.h, LaneRow):
+// 32 live lanes per wave instead of 8, and 12 workgroups per CU instead of 3.
+inline void run_encode(size_t bw, EncodeArgsB a, uint64_t units, int num_cus) {
+    a.epb = encode_edges_epb(a.D);
+    const bool global_rows = a.epb < 32;
+    DevBuf<float> scratch_f;
+    DevBuf<uint8_t> scratch_u;
+    size_t lds;
+    uint32_t per_cu;
+    if (global_rows) {
+        lds = encode_edges_lds_global(a.D);
+        per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(12, (150 * 1024) / lds));
+    } else {
+        lds = encode_edges_lds(a.D, a.epb);
+        per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(units, (uint64_t)num_cus * per_cu);
+    if (global_rows) {
+        scratch_f.alloc((size_t)grid * a.D * 32);
+        scratch_u.alloc((size_t)grid * a.D * 32);
+        a.scratch_f = scratch_f.p;
+        a.scratch_u = scratch_u.p;
+    }
+    auto go = [&](auto bw_t) {
+        constexpr int BW = decltype(bw_t)::value;
+        if (global_rows) launch_encode<BW, true>(a, grid, lds);
+        else launch_encode<BW, false>(a, grid, lds);
+    };
+    if (bw == 1) go(std::integral_constant<int, 1>());
+    else if (bw == 2) go(std::integral_constant<int, 2>());
+    else go(std::integral_constant<int, 4>());
+    HIP_CHECK(hipDeviceSynchronize());     // (the scratch is released on return)
 }
 
 // Graph, codes, upper layers.  `vecs` = n x dim input rows (host).  Fills `hi` (everything but the
@@ -239,15 +269,11 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
     {
         EncodeArgsB a{};
         a.x = dev.raw.p; a.nbr = d_nbr_new.p; a.centroid = d_centroid.p; a.n = n; a.dim = (uint32_t)dim; a.D = (uint32_t)D;
-        a.epb = encode_edges_epb((uint32_t)D);
         a.signs = d_signs.p; a.norm_factor = norm_factor; a.inv_sqrt_d = inv_sqrt_d; a.L = L; a.blocks = dev.blocks.p;
         a.own = d_own.p; a.own_stride = own_stride; a.own_meta = own_meta;
-        const size_t lds = encode_edges_lds(a.D, a.epb);
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
-        launch_encode_bits(bw, a, (uint32_t)std::min<uint64_t>(n, (uint64_t)num_cus * per_cu), lds);
+        run_encode(bw, a, n, num_cus);
         a.nbr = nullptr;
-        launch_encode_bits(bw, a, (uint32_t)std::min<uint64_t>((n + 31) / 32, (uint64_t)num_cus * per_cu), lds);
-        HIP_CHECK(hipDeviceSynchronize());
+        run_encode(bw, a, (n + 31) / 32, num_cus);
     }
     tm.lap("gather + edge / own codes");
 

@@ -786,12 +786,10 @@ int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* paren
         build::EncodeArgsB a{};
         const float df = (float)D;
         a.x = d_x.p; a.nbr = d_nbr.p; a.n = n; a.dim = (uint32_t)dim; a.D = (uint32_t)D;
-        a.epb = build::encode_edges_epb((uint32_t)D);
         a.signs = d_signs.p; a.norm_factor = 1.0f / (df * std::sqrt(df)); a.inv_sqrt_d = 1.0f / std::sqrt(df);
         a.L = L; a.blocks = d_blocks.p;
         a.dbg_values = d_vals.p; a.dbg_aux = d_aux.p; a.dbg_pops = d_pops.p;
-        build::launch_encode_bits(bits, a, 1, build::encode_edges_lds(a.D, a.epb));
-        HIP_CHECK(hipDeviceSynchronize());
+        build::run_encode(bits, a, 1, 1);
         HIP_CHECK(hipMemcpy(values, d_vals.p, cnt * D, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(aux, d_aux.p, cnt * 3 * 4, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(pops, d_pops.p, cnt * 2 * 4, hipMemcpyDeviceToHost));

@@ -147,22 +147,42 @@ struct LaneCode {
     uint32_t msb_pop, weighted_pop;
 };
 
-template <int BW>
-__device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, const float* rp, const float* ctab,
+// One lane's row of the rotated edge vectors and of their code bytes.  G = false: LDS rows (x[i] contiguous, the code
+// bytes contiguous); G = true: the workgroup's transposed scratch in HBM -- element i of edge e at T[i * 32 + e] and
+// the packed codes of coordinates 4j..4j+3 at U32[j * 32 + e] -- so that the 32 lanes of a wave read one 128-byte line
+// per coordinate and the number of resident waves is not set by LDS (D = 1024: 5 KB per edge, 8 edges per workgroup).
+template <bool G>
+struct LaneRow {
+    float* x;
+    uint8_t* u;
+    __device__ __forceinline__ float X(uint32_t i) const { return x[(size_t)i * (G ? 32 : 1)]; }
+    __device__ __forceinline__ void setX(uint32_t i, float v) const { x[(size_t)i * (G ? 32 : 1)] = v; }
+    __device__ __forceinline__ uint32_t U4(uint32_t i0) const {
+        return *reinterpret_cast<const uint32_t*>(u + (size_t)(i0 >> 2) * (G ? 128 : 4));
+    }
+    __device__ __forceinline__ void setU4(uint32_t i0, uint32_t v) const {
+        *reinterpret_cast<uint32_t*>(u + (size_t)(i0 >> 2) * (G ? 128 : 4)) = v;
+    }
+    __device__ __forceinline__ uint32_t Ub(uint32_t i) const { return u[(size_t)(i >> 2) * (G ? 128 : 4) + (i & 3)]; }
+    __device__ __forceinline__ void setUb(uint32_t i, uint32_t v) const { u[(size_t)(i >> 2) * (G ? 128 : 4) + (i & 3)] = (uint8_t)v; }
+};
+
+template <int BW, bool G>
+__device__ __forceinline__ LaneCode quantize_lane(const LaneRow<G> r, const float* rp, const float* ctab,
                                                   uint32_t D, float inv_sqrt_d) {
     LaneCode o{0.0f, 0.0f, 0u, 0u};
     if constexpr (BW == 1) {
         float l1 = 0.0f, ipcp = 0.0f;
         uint32_t pc = 0;
         for (uint32_t i = 0; i < D; ++i) {
-            const float v = x[i];
+            const float v = r.X(i);
             const bool pos = v >= 0.0f;
-            u[i] = pos ? 1 : 0;
+            r.setUb(i, pos ? 1u : 0u);
             l1 += __builtin_fabsf(v);
             pc += pos ? 1u : 0u;
         }
         if (rp)
-            for (uint32_t i = 0; i < D; ++i) ipcp += (u[i] ? 1.0f : -1.0f) * rp[i];
+            for (uint32_t i = 0; i < D; ++i) ipcp += (r.Ub(i) ? 1.0f : -1.0f) * rp[i];
         o.ip_qo = l1 * inv_sqrt_d;
         o.ip_cp = ipcp * inv_sqrt_d;
         o.msb_pop = o.weighted_pop = pc;
@@ -170,9 +190,9 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
     } else {
         constexpr int Ki = (1 << BW) - 1;
         const float K = (float)Ki;
-        float mn = x[0], mx = x[0];
+        float mn = r.X(0), mx = r.X(0);
         for (uint32_t i = 1; i < D; ++i) {
-            const float v = x[i];
+            const float v = r.X(i);
             if (v < mn) mn = v;
             if (v > mx) mx = v;
         }
@@ -185,7 +205,7 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
             float xv[4], c[4];
             uint32_t un = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = x[i0 + j];
+            for (int j = 0; j < 4; ++j) xv[j] = r.X(i0 + j);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int q = (int)__fmaf_rn(xv[j] - mn, inv_delta, 0.5f);
@@ -193,7 +213,7 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
                 un |= (uint32_t)q << (8 * j);
                 c[j] = ctab[q];
             }
-            *reinterpret_cast<uint32_t*>(u + i0) = un;
+            r.setU4(i0, un);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 dot = dot + c[j] * xv[j];
@@ -213,10 +233,10 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
         for (int iter = 0; iter < 10; ++iter) {
             bool changed = false;
             for (uint32_t i0 = 0; i0 < D; i0 += 4) {
-                const uint32_t up = *reinterpret_cast<const uint32_t*>(u + i0);
+                const uint32_t up = r.U4(i0);
                 float xv[4], oc[4], cl[4], ch[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = x[i0 + j];
+                for (int j = 0; j < 4; ++j) xv[j] = r.X(i0 + j);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ou = (int)((up >> (8 * j)) & 255u);
@@ -264,7 +284,7 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
                         changed = true;
                     }
                 }
-                if (un != up) *reinterpret_cast<uint32_t*>(u + i0) = un;
+                if (un != up) r.setU4(i0, un);
             }
             if (!changed) break;
             const float cs = nrm > 0.0f ? dot * dot / nrm : 0.0f;
@@ -274,11 +294,11 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
         float ipqo = 0.0f, ipcp = 0.0f;
         uint32_t msb = 0, wp = 0;
         for (uint32_t i0 = 0; i0 < D; i0 += 4) {
-            const uint32_t up = *reinterpret_cast<const uint32_t*>(u + i0);
+            const uint32_t up = r.U4(i0);
             float xv[4], rv[4], c[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                xv[j] = x[i0 + j];
+                xv[j] = r.X(i0 + j);
                 rv[j] = rp ? rp[i0 + j] : 0.0f;
                 c[j] = ctab[(up >> (8 * j)) & 255u];
             }
@@ -301,11 +321,18 @@ __device__ __forceinline__ LaneCode quantize_lane(const float* x, uint8_t* u, co
 
 // Squared norm of the lane's difference row as the reference's loop compiles (products rounded and added
 // in order for the vectorised part, fused for the dim % 4 scalar remainder).
-__device__ __forceinline__ float seq_norm_sq(const float* row, uint32_t dim) {
+template <bool G>
+__device__ __forceinline__ float seq_norm_sq(const LaneRow<G> r, uint32_t dim) {
     float s = 0.0f;
     const uint32_t body = dim - dim % 4;
-    for (uint32_t i = 0; i < body; ++i) s = s + row[i] * row[i];
-    for (uint32_t i = body; i < dim; ++i) s = __fmaf_rn(row[i], row[i], s);
+    for (uint32_t i0 = 0; i0 < body; i0 += 4) {      // four reads in flight, sums in order
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = r.X(i0 + j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = s + v[j] * v[j];
+    }
+    for (uint32_t i = body; i < dim; ++i) { const float v = r.X(i); s = __fmaf_rn(v, v, s); }
     return s;
 }
 
@@ -314,7 +341,9 @@ struct EncodeArgsB {
     const uint32_t* nbr;     // [n][32] neighbour ids (kInvalidNode = empty slot), or null (own codes)
     const float* centroid;   // own codes: [D] centroid (zero padded)
     uint64_t n;
-    uint32_t dim, D, epb;    // epb = edges per pass (LDS budget): 32, 16 or 8
+    uint32_t dim, D, epb;    // epb = edges per pass (LDS budget): 32, 16 or 8; 32 with the rows in HBM scratch
+    float* scratch_f;        // rows in HBM (encode_edges_kernel<BW, true>): [grid][D][32] floats ...
+    uint8_t* scratch_u;      // ... and [grid][D / 4][32] packed code dwords
     const float* signs;      // [3][D]
     float norm_factor, inv_sqrt_d;
     DevLayout L;
@@ -332,24 +361,31 @@ struct EncodeArgsB {
 __host__ __device__ inline size_t encode_edges_lds(uint32_t D, uint32_t epb) {
     return (size_t)(3 * D + 16 + 32) * 4 + (size_t)epb * (D + 1) * 4 + (size_t)epb * (D + 4);
 }
+// (rows in HBM scratch: only the parent, its rotation, the work row, the level table and the norms stay in LDS)
+__host__ __device__ inline size_t encode_edges_lds_global(uint32_t D) { return (size_t)(3 * D + 16 + 32) * 4; }
 inline uint32_t encode_edges_epb(uint32_t D) {
     uint32_t epb = 32;
     while (epb > 8 && encode_edges_lds(D, epb) > 72 * 1024) epb /= 2;
     return epb;
 }
 
-template <int BW>
+template <int BW, bool G>
 __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t D = a.D, dim = a.dim, epb = a.epb;
+    const uint32_t D = a.D, dim = a.dim, epb = G ? 32u : a.epb;
     float* pv = reinterpret_cast<float*>(smem);
     float* rp = pv + D;
     float* work = rp + D;
     float* ctab = work + D;
     float* nops = ctab + 16;
-    float* rot = nops + 32;
-    uint8_t* codes = reinterpret_cast<uint8_t*>(rot + (size_t)epb * (D + 1));
+    // rows of the edges of one pass: LDS (stride D + 1 floats / D + 4 bytes per edge), or this workgroup's transposed
+    // scratch in HBM
+    float* rot = G ? a.scratch_f + (size_t)blockIdx.x * D * 32 : nops + 32;
+    uint8_t* codes = G ? a.scratch_u + (size_t)blockIdx.x * D * 32 : reinterpret_cast<uint8_t*>(rot + (size_t)epb * (D + 1));
     const int lane = threadIdx.x;
+    auto F = [&](uint32_t e, uint32_t d) -> float& { return G ? rot[(size_t)d * 32 + e] : rot[(size_t)e * (D + 1) + d]; };
+    const LaneRow<G> myrow{G ? rot + (lane & 31) : rot + (size_t)(lane & 31) * (D + 1),
+                           G ? codes + (size_t)(lane & 31) * 4 : codes + (size_t)(lane & 31) * (D + 4)};
     const bool own = a.nbr == nullptr;
     if (lane < 16) {
         const float K = (float)((1 << BW) - 1);
@@ -382,12 +418,12 @@ __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
             for (uint32_t e = 0; e < m; ++e) {
                 const uint32_t vid = (uint32_t)__shfl((int)my_id, (int)(base + e));
                 const float* v = a.x + (size_t)vid * D;
-                for (uint32_t d = lane; d < D; d += 64) rot[e * (D + 1) + d] = d < dim ? v[d] - pv[d] : 0.0f;
+                for (uint32_t d = lane; d < D; d += 64) F(e, d) = d < dim ? v[d] - pv[d] : 0.0f;
             }
             __syncthreads();
             float nop = 0.0f;
             if ((uint32_t)lane < m) {
-                nop = __builtin_sqrtf(seq_norm_sq(rot + lane * (D + 1), dim));
+                nop = __builtin_sqrtf(seq_norm_sq<G>(myrow, dim));
                 nops[lane] = nop;
             }
             __syncthreads();
@@ -397,22 +433,21 @@ __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
                 const float ne = nops[e];
                 if (ne < neps) continue;               // degenerate edge: all-zero code, zero aux (uniform branch)
                 const float inv = 1.0f / ne;
-                for (uint32_t d = lane; d < D; d += 64) work[d] = rot[e * (D + 1) + d] * inv;
+                for (uint32_t d = lane; d < D; d += 64) work[d] = F(e, d) * inv;
                 __syncthreads();
                 rotate_scaled_lds(work, a.signs, D, a.norm_factor, lane);
-                for (uint32_t d = lane; d < D; d += 64) rot[e * (D + 1) + d] = work[d];
+                for (uint32_t d = lane; d < D; d += 64) F(e, d) = work[d];
                 __syncthreads();
             }
             // ---- one edge per lane: the sequential quantiser on its LDS row ------------------------
             LaneCode lc{0.0f, 0.0f, 0u, 0u};
             const bool live = (uint32_t)lane < m;
             const bool degenerate = live && nop < neps;
-            uint8_t* myu = codes + (size_t)lane * (D + 4);
             if (live) {
                 if (degenerate) {
-                    for (uint32_t i = 0; i < D; ++i) myu[i] = 0;
+                    for (uint32_t i = 0; i < D; i += 4) myrow.setU4(i, 0u);
                 } else {
-                    lc = quantize_lane<BW>(rot + lane * (D + 1), myu, own ? nullptr : rp, ctab, D, a.inv_sqrt_d);
+                    lc = quantize_lane<BW, G>(myrow, own ? nullptr : rp, ctab, D, a.inv_sqrt_d);
                 }
             }
             __syncthreads();
@@ -426,7 +461,7 @@ __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
                         for (uint32_t by = 0; by < words * 8; ++by) {
                             uint32_t v = 0;
                             for (uint32_t t = 0; t < 8 && 8 * by + t < D; ++t)
-                                v |= (uint32_t)((myu[8 * by + t] >> (BW - 1 - b)) & 1) << t;
+                                v |= (uint32_t)((myrow.Ub(8 * by + t) >> (BW - 1 - b)) & 1) << t;
                             o[(size_t)b * words * 8 + by] = (uint8_t)v;
                         }
                     *reinterpret_cast<float*>(o + a.own_meta) = nop;
@@ -439,7 +474,7 @@ __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
                         for (uint32_t w = 0; w < PW; ++w) {
                             uint32_t v = 0;
                             for (uint32_t t = 0; t < vbits; ++t)
-                                v |= (uint32_t)((myu[32 * w + t] >> (BW - 1 - b)) & 1) << t;
+                                v |= (uint32_t)((myrow.Ub(32 * w + t) >> (BW - 1 - b)) & 1) << t;
                             const uint32_t tt = b * PW + w;
                             size_t off;
                             if (a.L.wide) {
@@ -457,7 +492,7 @@ __global__ __launch_bounds__(64) void encode_edges_kernel(EncodeArgsB a) {
                     if (degenerate) aux = make_uint4(__float_as_uint(nop), 0u, 0u, 0u);
                     reinterpret_cast<uint4*>(blk + a.L.aux_off)[slot] = aux;
                     if (a.dbg_values) {
-                        for (uint32_t i = 0; i < D; ++i) a.dbg_values[((size_t)unit * 32 + slot) * D + i] = myu[i];
+                        for (uint32_t i = 0; i < D; ++i) a.dbg_values[((size_t)unit * 32 + slot) * D + i] = (uint8_t)myrow.Ub(i);
                         float* da = a.dbg_aux + ((size_t)unit * 32 + slot) * 3;
                         da[0] = nop; da[1] = degenerate ? 0.0f : lc.ip_qo; da[2] = degenerate ? 0.0f : lc.ip_cp;
                         a.dbg_pops[((size_t)unit * 32 + slot) * 2] = lc.msb_pop;
