@@ -11,6 +11,7 @@ struct BuiltDevice {            // the searchable index as the pipeline leaves i
     DevBuf<uint8_t> blocks;     // [n][stride] device blocks
     DevBuf<float> raw;          // [n][D] vectors, final order
     DevBuf<float> norm;         // [n]
+    std::vector<uint8_t> own_host;   // [n][nb_off]: every vertex' own code header (reference layout), for save()
 };
 
 inline size_t isqrt_sz(size_t n) { return (size_t)std::floor(std::sqrt((double)n)); }
@@ -286,29 +287,18 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
     const float upper_tau = ul.tau, upper_alpha = ul.alpha;
     tm.lap("upper layers (host, concurrent)");
 
-    // ---- host image: the reference's file layout derived from the device arrays ------------------------------
+    // ---- host side: vectors, norms, own-code headers (the reference-layout block image waits for save()) ----------
     hi.raw.resize(n * D);
     hi.norm_sq.resize(n);
     HIP_CHECK(hipMemcpy(hi.raw.data(), dev.raw.p, n * D * 4, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(hi.norm_sq.data(), dev.norm.p, n * 4, hipMemcpyDeviceToHost));
     hi.levels = std::move(levels_new);
-    hi.search_data.assign(n * hi.RL.vertex_bytes, 0);
-    {
-        const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (512u << 20) / L.stride));
-        std::vector<uint8_t> stage(chunk * L.stride), own(chunk * own_stride);
-        for (size_t base = 0; base < n; base += chunk) {
-            const size_t c = std::min(chunk, n - base);
-            HIP_CHECK(hipMemcpy(stage.data(), dev.blocks.p + base * L.stride, c * L.stride, hipMemcpyDeviceToHost));
-            HIP_CHECK(hipMemcpy(own.data(), d_own.p + base * own_stride, c * own_stride, hipMemcpyDeviceToHost));
-            parallel_for(c, 256, [&](size_t lo, size_t hi_) {
-                for (size_t v = lo; v < hi_; ++v) {
-                    uint8_t* dst = &hi.search_data[(base + v) * hi.RL.vertex_bytes];
-                    std::memcpy(dst, &own[v * own_stride], own_stride);
-                    repack_dev_to_ref(&stage[v * L.stride], L, hi.RL, dst + hi.RL.nb_off);
-                }
-            });
-        }
-    }
+    // The reference-layout image of the neighbour blocks (hi.search_data, 2.9 KB per vertex at D = 128, 17.7 KB at
+    // D = 1024) is only what save() writes: it is derived from the device blocks when a save asks for it
+    // (materialize_search_data), not here.  The own-code headers are small and come down now.
+    hi.search_data.clear();
+    dev.own_host.resize(n * (size_t)own_stride);
+    HIP_CHECK(hipMemcpy(dev.own_host.data(), d_own.p, n * (size_t)own_stride, hipMemcpyDeviceToHost));
     hi.upper = std::move(upper);
     hi.max_level = max_level;
     hi.entry = old_to_new[entry_old];
@@ -323,7 +313,7 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
     prof.graph_stats = gs;
     std::memcpy(hi.profile, &prof, 72);
     std::memset(hi.calib, 0, sizeof(hi.calib));
-    tm.lap("host image");
+    tm.lap("vectors, norms, own codes to the host");
 }
 
 // What the calibration needs from the device-resident index.

@@ -153,6 +153,7 @@ struct cph_index {
     // an index loaded from a native file keeps the mapping: vectors and own-code headers are served from it
     NativeMapping native_map;
     const uint8_t* own_view = nullptr;
+    std::vector<uint8_t> own_store;    // own-code headers of an index built here (own_view points into it)
     BatchSet sets[2];
     int last_set = 1;                  // the set handed out last (the two alternate)
     int last_search = -1;              // the set the most recent search went to
@@ -600,6 +601,7 @@ int cph_load(cph_index* h, const char* path) {
         h->host.load(path, h->D, h->bits, h->dim);  // commits only on success
         h->native_map.reset();
         h->own_view = nullptr;
+        std::vector<uint8_t>().swap(h->own_store);
         upload_arrays(h);
         upload_feeders(h);
         h->finalized = true;
@@ -649,6 +651,7 @@ int cph_load_native(cph_index* h, const char* path) {
         h->host = std::move(t);
         h->native_map = std::move(map);
         const uint8_t* base = static_cast<const uint8_t*>(h->native_map.base);
+        std::vector<uint8_t>().swap(h->own_store);
         h->own_view = base + nh.own_off;
         h->L = make_dev_layout((uint32_t)h->host.D, (uint32_t)h->host.bw);
         const size_t n = h->host.n;
@@ -685,6 +688,7 @@ int cph_build(cph_index* h, const float* vectors, uint64_t n) {
         h->host = HostIndex();
         h->native_map.reset();
         h->own_view = nullptr;
+        std::vector<uint8_t>().swap(h->own_store);
         h->finalized = false;
         h->d_blocks.release(); h->d_raw.release(); h->d_norm.release();
         for (auto& s : h->sets) release_scratch(s);
@@ -718,6 +722,9 @@ int cph_finalize(cph_index* h) {
         h->d_blocks = std::move(dev.blocks);
         h->d_raw = std::move(dev.raw);
         h->d_norm = std::move(dev.norm);
+        h->native_map.reset();
+        h->own_store = std::move(dev.own_host);
+        h->own_view = h->own_store.data();
         upload_feeders(h);
         build::DeviceIndexView view{h->d_blocks.p, h->d_raw.p, h->d_signs.p, h->L, h->norm_factor, h->inv_sqrt_d};
         build::calibrate(h->host, view, h->num_cus, verbose);
