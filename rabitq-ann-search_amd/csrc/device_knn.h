@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
     __shared__ uint32_t ci[kKnnTile * kKnnCap];
     __shared__ uint32_t cnt[kKnnTile];
     __shared__ float sig[kKnnTile];
-    __shared__ float bn_s[2][kKnnTile];                          // accumulator start values of the tile's columns (by tile parity)
+    __shared__ float bn_s[2][256];                               // |b|^2 of the tile's columns, by tile parity (first 128 of each)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -122,86 +122,136 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         const uint32_t qr = row0 + srow + 32 * i;
         qsrc[i] = a.q + (size_t)(qr < a.nq ? qr : a.nq - 1) * D + skq;
     }
+    // Software pipeline at HALF-chunk granularity.  A chunk's 64 MFMAs split into two halves of 32 (k-steps j = 0,1 and
+    // j = 2,3), each with its own operand registers (2 A + 8 B reads of 16 B: 40 registers per half, the 80 the kernel
+    // had for a whole chunk).  While a half's MFMAs run, the other half's operands are read from LDS:
+    //   first half of chunk g   (operands op0):  read op1 = (g, second half);  stage chunk g+1 into the other image;
+    //                                            fetch chunk g+2 from HBM
+    //   --- barrier: image(g+1) published, every wave done reading image(g) ---
+    //   second half of chunk g  (operands op1):  read op0 = (g+1, first half)
+    // so no LDS round trip, no staging and no address arithmetic stands in front of the matrix pipe any more (one wave
+    // per SIMD: nothing else would cover them -- they were ~2,000 of every 6,100 cycles per chunk); what remains exposed
+    // is the barrier's skew.  Same registers, same LDS, same arithmetic.
     knn_f32x4 pq[4], pb[4];
-    float pbn = 0.0f;                   // -|b|^2 / 2 of column tid of the tile being fetched (chunk 0 only)
-    auto fetch = [&](uint32_t tile, uint32_t ch) {
-        const uint32_t k0 = ch * kKnnKC;
-        if (ch == 0 && tid < kKnnTile) {
-            const uint32_t col = tile * kKnnTile + tid;
-            pbn = col < a.nb ? -0.5f * a.bnorm[col] : NEG_INF;
+    float pbn = 0.0f;                   // |b|^2 of column (tid & 127) of the tile being fetched
+    uint32_t f_tile = 0, f_ch = 0;      // the chunk the next fetch() brings in (past the end: the last tile again, unused)
+    uint32_t f_tile_staged = 0;
+    auto fetch = [&]() {
+        const uint32_t k0 = f_ch * kKnnKC;
+        f_tile_staged = f_tile;
+        {   // every chunk, every thread, no branch (a half is one basic block, or the interleave below falls apart);
+            // columns past the end get +inf: their accumulators start at -inf and never pass the filter
+            const uint32_t col = f_tile * kKnnTile + (tid & (kKnnTile - 1));
+            const float bn = a.bnorm[col < a.nb ? col : a.nb - 1];
+            pbn = col < a.nb ? bn : __builtin_inff();
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t br = tile * kKnnTile + srow + 32 * i;
+            const uint32_t br = f_tile * kKnnTile + srow + 32 * i;
             pq[i] = *reinterpret_cast<const knn_f32x4*>(qsrc[i] + k0);
             pb[i] = *reinterpret_cast<const knn_f32x4*>(a.b + (size_t)(br < a.nb ? br : a.nb - 1) * D + skq + k0);
         }
+        const bool wrap = f_ch + 1 == nchunk;
+        f_ch = wrap ? 0 : f_ch + 1;
+        f_tile = (wrap && f_tile + 1 < ntile) ? f_tile + 1 : f_tile;
     };
-    auto stage = [&](int buf, bool first_chunk, uint32_t tile) {
-        if (first_chunk && tid < kKnnTile) bn_s[tile & 1][tid] = pbn;
+    auto stage = [&](int buf) {         // what fetch() brought in -> image `buf` (and its tile's column norms)
+        bn_s[f_tile_staged & 1][tid] = pbn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<knn_f32x4*>(&Qs[buf][(srow + 32 * i) * kKnnLd + skq]) = pq[i];
             *reinterpret_cast<knn_f32x4*>(&Bs[buf][(srow + 32 * i) * kKnnLd + skq]) = pb[i];
         }
     };
-
+    const int wrow = wave * 32;         // first tile row of this wave
+    // operand registers of half a chunk: lane (h, c) reads its row's k = 8j + 4h .. + 3 for j = 2 half, 2 half + 1
+    struct Ops { knn_f32x4 av[2], bv[2][4]; };
+    auto read_ops = [&](int buf, int half, Ops& o) {
+        const float* Qb = Qs[buf];
+        const float* Bb = Bs[buf];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * half + jj;
+            o.av[jj] = *reinterpret_cast<const knn_f32x4*>(&Qb[(wrow + c) * kKnnLd + 8 * j + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                o.bv[jj][t] = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
+        }
+    };
     knn_f32x16 acc[4];
+    auto mfma_half = [&](const Ops& o) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].x, o.bv[jj][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].y, o.bv[jj][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].z, o.bv[jj][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].w, o.bv[jj][t].w, acc[t], 0, 0, 0);
+            }
+        }
+    };
     float sg[16];                       // thresholds of this lane's 16 rows
 #pragma unroll
     for (int i = 0; i < 16; ++i) sg[i] = NEG_INF;
-    const int wrow = wave * 32;         // first tile row of this wave
 
-    fetch(0, 0);
-    stage(0, true, 0);
-    __syncthreads();                    // first operand image, cnt and sig are in place
+    // prologue: image(0) staged and published, chunk 1 in flight, first-half operands of chunk 0 in registers
+    Ops op0, op1;
+    fetch();
+    stage(0);
+    fetch();
+    __syncthreads();                    // image(0), cnt and sig are in place
+    read_ops(0, 0, op0);
     int buf = 0;
     for (uint32_t tile = 0; tile < ntile; ++tile)
     for (uint32_t ch = 0; ch < nchunk; ++ch) {
         if (ch == 0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                // (staged through LDS with the tile's first operand image: a global load here would be a full memory
-                // round trip in front of every tile with nothing to overlap it -- it was a third of the kernel's time)
-                const float init = bn_s[tile & 1][t * 32 + c];
+                // (the column norms come through LDS with the tile's first operand image: a global load here would be a
+                // memory round trip in front of every tile)
+                const float init = -0.5f * bn_s[tile & 1][t * 32 + c];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[t][i] = init;
             }
         }
-        // the next chunk's loads are in flight during the MFMAs below
-        // (unconditionally: behind the last chunk the last tile is fetched once more and never used)
-        const bool wrap = ch + 1 == nchunk;
-        const uint32_t ntl = wrap ? (tile + 1 < ntile ? tile + 1 : tile) : tile, nch = wrap ? 0 : ch + 1;
-        fetch(ntl, nch);
-        const float* Qb = Qs[buf];
-        const float* Bb = Bs[buf];
-        // All 20 operand reads of the chunk are issued before the first of its 64 MFMAs: one exposed LDS round trip
-        // per chunk instead of one in front of every group of four (with one wave per SIMD nothing else would
-        // cover them).
-        knn_f32x4 av[4], bv[4][4];
+        // ---- first half: MFMAs on op0; behind them op1 of this chunk, the staging of the next chunk, the fetch of the
+        // one after -----------------------------------------------------------------------------------------------
+        __builtin_amdgcn_sched_barrier(0);
+        read_ops(buf, 1, op1);
+        stage(buf ^ 1);
+        fetch();
+        mfma_half(op0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            av[j] = *reinterpret_cast<const knn_f32x4*>(&Qb[(wrow + c) * kKnnLd + 8 * j + 4 * h]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                bv[j][t] = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
+        for (int i = 0; i < 10; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
         }
-        __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink every read back in front of its first use)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].x, bv[j][t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].y, bv[j][t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].z, bv[j][t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j].w, bv[j][t].w, acc[t], 0, 0, 0);
-            }
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
         }
-        // The other image was last read one chunk ago and every wave has passed a barrier since: it can
-        // be overwritten now; ONE barrier per chunk then publishes it.
-        stage(buf ^ 1, wrap, tile + 1);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // VALU (addresses of the fetch)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         buf ^= 1;
+        // ---- second half: MFMAs on op1; behind them the first-half operands of the next chunk -------------------
+        read_ops(buf, 0, op0);
+        mfma_half(op1);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (ch + 1 != nchunk) continue;
 
         // ---- tile finished: filter its 4 x (32 x 32) keys against the row thresholds ----------
