@@ -31,12 +31,13 @@
 // instruction needs -- the order in which k is summed is irrelevant to an exact-kNN list.  The 36-float
 // stride makes the 16 rows of each ds_read_b128 lane group land on 16 distinct 4-bank spans.
 //
-// Where the time goes (stamps per phase, 262,144 x 128): MFMA issue 48 %, the tile epilogue (filter) 18 %, and per
-// 32-float chunk about 2,000 cycles of operand reads, staging and barrier that one wave per SIMD cannot hide behind
-// its own 4,100 cycles of MFMAs.  A three-stage software pipeline (operands of chunk g+1 read from LDS during chunk g's
-// MFMAs, global prefetch two chunks deeper, sched_group_barrier interleave) was built and measured: the second operand
-// set does not fit next to accumulators, prefetch and thresholds in 256 architectural registers, the compiler parks
-// it in AGPRs and moves it back and forth (hundreds of v_accvgpr moves per chunk): 70 TF/s against 82.  Reverted.
+// Where the time goes (s_memtime stamps per phase, 262,144 x 128, after the half-chunk pipeline below): the chunk loop
+// runs at 77 % of the matrix pipe's rate (second halves fully covered, first halves +25 %, the barrier ~350 cycles per
+// chunk); the tile epilogue -- accumulator reads, threshold test, the appends of the 40 % of the 32 x 32 sub-tiles that
+// have one, accumulator re-initialisation -- is ~6,000 cycles per tile next to the tile's 16,400 cycles of MFMAs at
+// D = 128 (a tenth of that share at D = 1024).  Earlier attempts: a whole second operand set (three-stage pipeline)
+// does not fit in 256 architectural registers -- the compiler parks it in AGPRs and shuttles it with hundreds of
+// v_accvgpr moves per chunk, 70 TF/s; two workgroups per CU spill around the selection code.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -257,10 +258,13 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
         // ---- tile finished: filter its 4 x (32 x 32) keys against the row thresholds ----------
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            bool any = false;
+            // "does any of my 16 keys beat its row's threshold" as one max-reduction and one compare: sixteen compares
+            // into scalar registers OR-ed together made a dependent chain through the scalar unit (a key of a column past
+            // the end is -inf: against a threshold that is still -inf the difference is NaN, which v_max drops)
+            float lead = NEG_INF;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) any |= acc[t][i] > sg[i];
-            if (!__any(any)) continue;
+            for (int i = 0; i < 16; ++i) lead = __builtin_fmaxf(lead, acc[t][i] - sg[i]);
+            if (!__any(lead > 0.0f)) continue;
             const uint32_t col = tile * kKnnTile + t * 32 + c;
             bool compacted = false;
 #pragma unroll
