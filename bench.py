@@ -16,12 +16,15 @@ returns the whole batch: src/bindings.cpp:199-211).  Queries shard across ranks,
 replicated (weak scaling: nq per GPU fixed).
 
 Other configs (parity-backed lines for profiles/, not the driver's default):
-  c3     GIST1M-class 1M x 960 (D=1024), 4-bit, two-stage MSB pipeline, generic-D search kernel
+  c3     GIST1M-class 1M x 960 (D=1024), 4-bit, two-stage MSB pipeline, static <4,1024> search kernel
   c4     Deep10M-class 10M x 96 (D=128), 4-bit
   c5     streaming FastScan over the largest D=1024 / 2-bit block set that fits this GPU
   recall Gaussian 100k x 128, 2-bit, k=20: a workload where the reference algorithm meets recall@10 >= 0.95
 
 The JSON line also carries
+  * qps_at_recall_gate (c2, N = 1): the metric's gate, recall@10 >= 0.95, is not reachable for the reference algorithm
+    on the SIFT-like data (our ids are the reference's bit for bit), so a short child run of the `recall` config --
+    where it is -- is condensed into this object: QPS, recall, kernel fraction of HBM peak,
   * fastscan_stream: the streaming FastScan kernel on synthetic neighbour blocks of the config's
     shape (metric part 2: distances/s vs the HBM roofline),
   * roofline: the dominant kernel of the timed region (the persistent search kernel): algorithmic
