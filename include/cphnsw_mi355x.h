@@ -93,6 +93,13 @@ int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t di
 int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* parent, const float* nbrs, uint64_t cnt,
                      uint8_t* values, float* aux, uint32_t* pops);
 
+/* Self-test hook for the beam's heap routines (wave-parallel std::push_heap / std::pop_heap with the first 255
+ * entries in LDS and the rest in HBM, search/rabitq_search.hpp:53-58, :79-80): runs `ops` (1 = push the next
+ * (key, id), 0 = pop) on one wave and returns the heap array; the test compares it with libstdc++'s on the same
+ * sequence.  out_keys / out_ids hold n_push entries. */
+int cph_debug_heap_ops(int device, const uint8_t* ops, uint64_t n_ops, const float* keys, const uint32_t* ids, uint64_t n_push,
+                       float* out_keys, uint32_t* out_ids, uint32_t* out_size);
+
 /* ---- search ---------------------------------------------------------------------- */
 /* queries: host, row-major [n][dim] float32.  ids/dist: host, [n][k], rows shorter than k
  * padded with -1 / FLT_MAX (src/bindings.cpp:202-210). */

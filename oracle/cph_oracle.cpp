@@ -699,6 +699,30 @@ int orc_l2(int D, const float* a, const float* b, float* out) { *out = l2sq8(D, 
 // (pinned bit-for-bit against ref_encode_edges by tests/test_oracle_golden.py).
 // values u8[cnt][D], aux f32[cnt][3] = {nop, ip_qo, ip_cp}, pops u32[cnt][2] = {msb, weighted}.
 // ---------------------------------------------------------------------------------
+// The beam as the reference keeps it -- std::priority_queue<BeamEntry, vector, greater> is std::push_heap / std::pop_heap
+// on a vector (search/rabitq_search.hpp:53-58, :79-80) -- driven by an explicit operation list (1 = push the next
+// (key, id), 0 = pop), with libstdc++'s own algorithms: the reference for the GPU heap routines' self-test
+// (cph_debug_heap_ops).  Returns the heap array after the last operation.
+extern "C" int orc_std_heap_ops(const uint8_t* ops, uint64_t n_ops, const float* keys, const uint32_t* ids,
+                                float* out_keys, uint32_t* out_ids, uint32_t* out_size) {
+    std::vector<BeamEntry> h;
+    size_t next = 0;
+    auto comp = [](const BeamEntry& a, const BeamEntry& b) { return a.est > b.est; };
+    for (uint64_t j = 0; j < n_ops; ++j) {
+        if (ops[j]) {
+            h.push_back(BeamEntry{keys[next], 0.0f, ids[next]});
+            ++next;
+            std::push_heap(h.begin(), h.end(), comp);
+        } else if (!h.empty()) {
+            std::pop_heap(h.begin(), h.end(), comp);
+            h.pop_back();
+        }
+    }
+    for (size_t i = 0; i < h.size(); ++i) { out_keys[i] = h[i].est; out_ids[i] = h[i].id; }
+    *out_size = (uint32_t)h.size();
+    return 0;
+}
+
 int orc_encode_edges(int dim, int D, int bits, const float* parent, const float* nbrs, int cnt,
                      uint8_t* values, float* aux, uint32_t* pops) {
     Rotation rot(D);

@@ -2,6 +2,6 @@
 
     from cphnsw_mi355x import CPIndex      # drop-in for `from cphnsw import CPIndex`
 """
-from .index import CPIndex, FastScanStream, encode_edges, knn_bruteforce  # noqa: F401
+from .index import CPIndex, FastScanStream, encode_edges, heap_ops_debug, knn_bruteforce  # noqa: F401
 
-__all__ = ["CPIndex", "FastScanStream", "encode_edges", "knn_bruteforce"]
+__all__ = ["CPIndex", "FastScanStream", "encode_edges", "heap_ops_debug", "knn_bruteforce"]

@@ -25,6 +25,8 @@ SYMBOLS = {
     "cph_finalize": (C.c_int, [C.c_void_p]),
     "cph_knn_bruteforce": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                                      C.c_void_p, C.c_void_p]),
+    "cph_debug_heap_ops": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "cph_encode_edges": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "cph_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),

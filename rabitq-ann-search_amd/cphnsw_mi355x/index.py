@@ -259,6 +259,23 @@ def encode_edges(parent, nbrs, bits, device=None):
     return vals, aux, pops
 
 
+def heap_ops_debug(ops, keys, ids, device=None):
+    """Self-test hook: runs a push (1) / pop (0) sequence through the beam's wave-parallel heap routines (first 255
+    entries in LDS, the rest in HBM) and returns the heap array (keys f32, ids u32)."""
+    ops = np.ascontiguousarray(ops, np.uint8)
+    keys = np.ascontiguousarray(keys, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    n_push = int(ops.sum())
+    assert len(keys) == n_push and len(ids) == n_push
+    ok = np.zeros(max(1, n_push), np.float32)
+    oi = np.zeros(max(1, n_push), np.uint32)
+    sz = np.zeros(1, np.uint32)
+    dev = _default_device() if device is None else int(device)
+    _lib.check(_lib.lib().cph_debug_heap_ops(dev, ops.ctypes.data, len(ops), keys.ctypes.data, ids.ctypes.data, n_push,
+                                             ok.ctypes.data, oi.ctypes.data, sz.ctypes.data))
+    return ok[:sz[0]].copy(), oi[:sz[0]].copy()
+
+
 def _default_device():
     """One process per GPU: LOCAL_RANK selects the device when launched by torch.distributed.run."""
     import os

@@ -23,6 +23,7 @@
 #include "device_fastscan.h"
 #include "device_search.h"
 #include "device_stream.h"
+#include "device_heap_test.h"
 #include "host_index.h"
 #include "native_file.h"
 #include "builder_pipeline.h"
@@ -760,6 +761,37 @@ int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t di
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) cus = prop.multiProcessorCount;
         build::gpu_knn(queries ? q.data() : nullptr, queries ? qn.data() : nullptr, nq, x.data(), nrm.data(), n, D,
                        cus, ids, dist);
+    });
+}
+
+int cph_debug_heap_ops(int device, const uint8_t* ops, uint64_t n_ops, const float* keys, const uint32_t* ids, uint64_t n_push,
+                       float* out_keys, uint32_t* out_ids, uint32_t* out_size) {
+    return guarded([&] {
+        if (!ops || !out_keys || !out_ids || !out_size || n_ops == 0 || n_ops > 0x7FFFFFFFull) throw InvalidArg("bad arguments");
+        if (n_push && (!keys || !ids)) throw InvalidArg("bad arguments");
+        uint64_t pushes = 0;
+        for (uint64_t i = 0; i < n_ops; ++i) pushes += ops[i] ? 1 : 0;
+        if (pushes != n_push) throw InvalidArg("n_push must equal the number of push operations");
+        HIP_CHECK(hipSetDevice(device));
+        DevBuf<uint8_t> d_ops(n_ops);
+        DevBuf<float> d_keys(std::max<uint64_t>(1, n_push)), d_ok(std::max<uint64_t>(1, n_push));
+        DevBuf<uint32_t> d_ids(std::max<uint64_t>(1, n_push)), d_oi(std::max<uint64_t>(1, n_push)), d_sz(1);
+        DevBuf<uint4> d_spill(std::max<uint64_t>(1, n_push) + 64);
+        HIP_CHECK(hipMemcpy(d_ops.p, ops, n_ops, hipMemcpyHostToDevice));
+        if (n_push) {
+            HIP_CHECK(hipMemcpy(d_keys.p, keys, n_push * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(d_ids.p, ids, n_push * 4, hipMemcpyHostToDevice));
+        }
+        HeapTestArgs a{d_ops.p, d_keys.p, d_ids.p, (uint32_t)n_ops, d_spill.p, d_ok.p, d_oi.p, d_sz.p};
+        hipLaunchKernelGGL(heap_selftest_kernel, dim3(1), dim3(64), 0, nullptr, a);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out_size, d_sz.p, 4, hipMemcpyDeviceToHost));
+        if (*out_size > n_push) throw std::runtime_error("heap self-test: size out of range");
+        if (*out_size) {
+            HIP_CHECK(hipMemcpy(out_keys, d_ok.p, (size_t)*out_size * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(out_ids, d_oi.p, (size_t)*out_size * 4, hipMemcpyDeviceToHost));
+        }
     });
 }
 

@@ -130,6 +130,17 @@ class _Hooks:
         assert f(dim, D, bits, parent, nbrs, cnt, vals, aux, pops) == 0
         return vals, aux, pops
 
+    def std_heap_ops(self, ops, keys, ids):
+        """libstdc++ std::push_heap / std::pop_heap (comparator: greater on the key) over an operation list."""
+        ops = _c(ops, np.uint8); keys = _c(keys, np.float32); ids = _c(ids, np.uint32)
+        ok = np.zeros(max(1, len(keys)), np.float32)
+        oi = np.zeros(max(1, len(keys)), np.uint32)
+        sz = np.zeros(1, np.uint32)
+        f = self._f("std_heap_ops")
+        f.argtypes = [u8p, C.c_uint64, f32p, u32p, f32p, u32p, u32p]
+        assert f(ops, len(ops), keys, ids, ok, oi, sz) == 0
+        return ok[:sz[0]].copy(), oi[:sz[0]].copy()
+
     def dot(self, a, b):
         out = np.zeros(1, np.float32)
         f = self._f("dot")

@@ -253,6 +253,30 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
+@pytest.mark.parametrize("n_fill", [1, 2, 3, 7, 254, 255, 256, 257, 300, 511, 512, 4095, 4096, 4097, 8191, 8192, 9000, 70000])
+def test_beam_heap_routines_move_like_libstdcxx(cph, oracle, n_fill):
+    """The beam's wave-parallel heap routines (heap_push_wave / heap_pop_wave in LDS, beam_push_hybrid / beam_pop_hybrid
+    once it spills to HBM: windows of five levels) against libstdc++'s std::push_heap / std::pop_heap on the same
+    operation list: n_fill pushes, then a random mix of pops and pushes, then pops down across the LDS boundary.  Keys
+    are drawn from few distinct values, so equal keys -- whose order a heap's exact element movement decides -- are
+    everywhere.  The whole heap array must match after the last operation, element for element."""
+    rng = np.random.default_rng(1000 + n_fill)
+    for distinct in (8, 1 << 20):
+        mix = rng.integers(0, 2, size=600).astype(np.uint8)
+        drain = np.zeros(min(n_fill + 200, 700), np.uint8)
+        refill = np.ones(300, np.uint8)
+        tail = rng.integers(0, 3, size=400).astype(np.uint8).clip(0, 1)      # pushes twice as likely as pops
+        ops = np.concatenate([np.ones(n_fill, np.uint8), mix, drain, refill, tail])
+        n_push = int(ops.sum())
+        keys = rng.integers(0, distinct, size=n_push).astype(np.float32)
+        ids = np.arange(n_push, dtype=np.uint32)
+        gk, gi = cph.heap_ops_debug(ops, keys, ids)
+        wk, wi = oracle.std_heap_ops(ops, keys, ids)
+        assert len(gk) == len(wk), (n_fill, distinct, len(gk), len(wk))
+        assert np.array_equal(gi, wi), (n_fill, distinct, int((gi != wi).sum()))
+        assert gk.tobytes() == wk.tobytes()
+
+
 @pytest.mark.parametrize("k", [256, 257, 300, 1000])
 def test_large_k_result_heap(cph, gold, k):
     """k past the 256 entries the wave-parallel result-heap routines cover (kWaveHeapMax): the heap falls back to the
