@@ -10,16 +10,17 @@
 // ever written to HBM.
 //
 // Geometry.  One workgroup (4 waves, one per SIMD) = 128 query rows against every base row, in
-// 128-column tiles; the K dimension is staged through LDS in chunks of 32 floats with the next
-// chunk's global loads in flight during the current chunk's 64 MFMAs per wave (register prefetch).
+// 128-column tiles; the K dimension is staged through LDS in chunks of 32 floats (64 MFMAs per wave and chunk),
+// software-pipelined at half-chunk granularity: operand reads, staging of the next chunk and the global loads of the
+// one after run behind the MFMAs (see the main loop).
 // Wave w owns rows 32w..32w+31 of the tile and computes all 128 columns for them (1 x 4 MFMA tiles of
 // 32 x 32), so the per-row candidate lists are touched by one wave only and the selection needs no
 // workgroup barrier.
 //
 // Ranking key.  The accumulators start at -|b|^2 / 2, so a finished accumulator holds
 //     s = q.b - |b|^2 / 2,        |q - b|^2 = |q|^2 - 2 s,
-// and "nearer" is "larger s" with a per-row constant removed: the filter is ONE v_cmp per element
-// against the row's threshold (kept in registers).  Passing elements are appended to the row's
+// and "nearer" is "larger s" with a per-row constant removed: the filter is a subtract and a max per element against
+// the row's threshold (kept in registers), one compare per 32 x 32 sub-tile.  Passing elements are appended to the row's
 // 64-entry LDS list; only when an append would not fit is the list sorted and cut back to its best 32 by
 // rank computation (every lane holds one entry and counts the entries that beat it, broadcast through
 // v_readlane), which also yields the new threshold: the 32nd best key seen so far.  Between two sorts the
