@@ -485,14 +485,10 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     const bool ordered = h->dev_max_level > 0 && h->order_queries;
     if (ordered) {
         slots = std::min<uint32_t>(nq, max_slots);
-        // A batch that fits the slots runs in the kernel's latency mode (one wave per query, next-top prefetch).
-        // That pays for a few hundred queries; from there on three quarters of the batch in slots and the rest queued
-        // behind them -- the order starts with the longest queries, the short ones fill the gaps, no prefetch traffic --
-        // is faster (C2: 1,000 queries 1.29 -> 1.19 ms, 5,000 1.77 -> 1.53 ms; C3: equal to 5 % faster;
-        // scripts/lat_threshold.py)
-        constexpr uint32_t kLatencyBatch = 768;
-        if (!h->want_slots && nq > kLatencyBatch)
-            slots = std::min<uint32_t>(max_slots, std::max<uint32_t>(kLatencyBatch, (uint32_t)((3ull * nq) / 4)));
+        // A batch that would fit the slots still gains from a short queue: the order starts with the longest queries,
+        // the last eighth -- the shortest -- fills the gaps they leave (C2: 4,000 queries 1.35 -> 1.29 ms, 6,000
+        // queries 1.72 -> 1.53 ms; equal at 1,000; scripts/slot_fraction_sweep.py)
+        if (!h->want_slots && nq >= 512) slots = std::min<uint32_t>(max_slots, nq - nq / 8);
     }
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
     uint64_t cap = h->want_cap ? h->want_cap : std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(n + 1, 1u << 16));

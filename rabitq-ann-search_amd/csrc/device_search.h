@@ -454,7 +454,7 @@ __device__ __forceinline__ float bcast_f32(float v) {
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512 or D*4] (popped vertex's vector, LDS-DMA target) |
 // pf[256] (prefetch sink, latency mode) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsTail = 256 + 128 + 64 + 128 + 16;      // pf | exact | list | slack | ratio
+constexpr uint32_t kLdsTail = 256 + 128 + 64 + 128 + 16;      // (spare) | exact | list | slack | ratio
 // vec[] holds the popped vertex' whole vector in the instantiations with a compile-time D (LDS-DMA target)
 __host__ __device__ inline uint32_t search_vec_bytes(uint32_t D, bool static_d) { return static_d ? D * 4 : 512; }
 __host__ __device__ inline bool search_static_d(uint32_t D) { return D == 128 || D == 1024; }
@@ -478,10 +478,6 @@ __device__ __forceinline__ uint32_t lds_offset(const void* p) {
 }
 __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
-}
-
-__device__ __forceinline__ void lds_dma4(const void* g, uint32_t lds_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_off) : "memory");
 }
 
 // Waves per SIMD: 6 (<= 80 VGPRs) for the static D = 128 instantiations, 5 (<= 96 VGPRs) for the
@@ -528,7 +524,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     // LDS (none here), so this is a compile-time constant -- a generic-to-LDS pointer cast would be
     // re-derived (with its null check) by ten scalar instructions in every expansion
     const uint32_t vec_off = __builtin_amdgcn_groupstaticsize() + PW * 16 + D * 4;
-    const uint32_t pf_off = vec_off + vsz;
     const uint32_t slot = blockIdx.x;
     uint32_t* bm = CPH_COLD(bitmaps) + (size_t)slot * CPH_COLD(bm_words);
     uint32_t* logi = CPH_COLD(log_ids) + (size_t)slot * a.cap;
@@ -538,14 +533,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     const float FMAX = 3.402823466e+38f;
     if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
-    // Latency mode: a batch that fits the resident slots has no queue behind it -- bandwidth is free and
-    // every query is on the critical path, so the next beam top is prefetched as the reference does
-    // (:124-128).  With a queue behind the slots that prefetch only costs bandwidth (see below).
-    // (Switching to it when a larger batch starts to drain was tried: any way of telling thousands of
-    // running waves that the queue is empty -- polling the counter or a flag word -- cost far more than
-    // the prefetch gains in the drain phase.  So was a per-query latency mode for the head of the launch
-    // order -- the longest queries -- or for its tail -- the ones that start as the queue runs dry: both
-    // 1-4 % slower on the 10k batch, profiles/r2_lat_sweep.jsonl.)
+    // No next-top prefetch (the reference has one, :124-128).  It was kept for batches that fit the resident slots
+    // ("latency mode") until the end of round 2, when it measured as a loss at every batch size with the current kernel:
+    // a single query 718 -> 622 us per call without it, 32 queries 960 -> 829 us, 2,000 queries 1,396 -> 1,129 us
+    // (scripts/slot_fraction_sweep.py, scripts/single_query_latency.py) -- the ~40 % of predictions that a later push
+    // invalidates cost bandwidth and issue slots, and the pop already runs under the block's own latency.  (Earlier:
+    // switching it on when a larger batch starts to drain, or per query for the head or the tail of the launch order,
+    // were 1-4 % slower on the 10k batch or far worse, profiles/r2_lat_sweep.jsonl.)
     // What bounds the throughput phase is instruction issue, not latency: per expansion a wave issues ~320 vector and
     // ~270 scalar instructions (profiles/r2_pmc_search_summary.txt), and with six waves on a SIMD that is ~85 % of
     // the SIMD's vector issue slots (one wave64 instruction per four cycles) while the queue is full.  Hiding more
@@ -555,7 +549,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     // loop head, i.e. wait for them: 2.50 ms.  Fewer instructions per expansion is the only lever left.
     const uint32_t* nq_dev = CPH_COLD(nq_dev);
     const uint32_t nq = nq_dev ? *nq_dev : CPH_COLD(nq);
-    const bool lat = nq <= gridDim.x;
     for (;;) {
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(CPH_COLD(counter), 1u);
@@ -710,23 +703,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
             if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // Software prefetch of the next beam top, in latency mode only (see `lat`): one dword per
-            // 64-B line of its block and vector by LDS-DMA into a sink that is never read.  In the
-            // throughput phase the ~40 % of predictions that a later push invalidates cost HBM
-            // bandwidth that is the scarcer resource there (22.9 -> 21.1 ms per 100k queries without).
-            // The compiler does not know this load: it goes right behind the probe, the only load of
-            // this expansion still to be waited for (with vmcnt(0)).
-            if (lat && beam_size > 0) {
-                const uint32_t next_id = bcast_u32(heap.lds(0).z);
-                const uint32_t bl_all = a.L.stride >> 6, vl_all = (D * 4u) >> 6;
-                const uint32_t blk_lines = bl_all < 48u ? bl_all : 48u;
-                const uint32_t vec_lines = vl_all < 64u - blk_lines ? vl_all : 64u - blk_lines;
-                const uint8_t* nblk = a.blocks + (size_t)next_id * a.L.stride;
-                const uint8_t* nvec = reinterpret_cast<const uint8_t*>(a.raw + (size_t)next_id * D);
-                const uint8_t* src = (uint32_t)lane < blk_lines ? nblk + (uint32_t)lane * 64u
-                                                                : nvec + ((uint32_t)lane - blk_lines) * 64u;
-                if ((uint32_t)lane < blk_lines + vec_lines) lds_dma4(src, pf_off);
-            }
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
