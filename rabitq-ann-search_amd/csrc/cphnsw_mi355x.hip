@@ -485,10 +485,11 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     const bool ordered = h->dev_max_level > 0 && h->order_queries;
     if (ordered) {
         slots = std::min<uint32_t>(nq, max_slots);
-        // A batch that would fit the slots still gains from a short queue: the order starts with the longest queries,
-        // the last eighth -- the shortest -- fills the gaps they leave (C2: 4,000 queries 1.35 -> 1.29 ms, 6,000
-        // queries 1.72 -> 1.53 ms; equal at 1,000; scripts/slot_fraction_sweep.py)
-        if (!h->want_slots && nq >= 512) slots = std::min<uint32_t>(max_slots, nq - nq / 8);
+        // A batch that fills more than half of the slots gains from a short queue: the order starts with the longest
+        // queries, the last eighth -- the shortest -- fills the gaps they leave (C2, 6,144 slots: 4,000 queries
+        // 1.37 -> 1.31 ms, 6,000 queries 1.65 -> 1.61 ms; below 3,000 queries all resident is 0-7 % faster;
+        // scripts/slot_fraction_sweep.py, profiles/r2_slot_fraction.md)
+        if (!h->want_slots && nq > max_slots / 2) slots = std::min<uint32_t>(max_slots, nq - nq / 8);
     }
     const uint64_t bm_bytes = ((n + 31) / 32) * 4;
     uint64_t cap = h->want_cap ? h->want_cap : std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(n + 1, 1u << 16));
