@@ -1,5 +1,7 @@
-"""Kernel time of mid-sized batches in latency mode (one wave per query, next-top prefetch: the default when the batch
-fits the resident slots) against throughput mode (fewer slots than queries, no prefetch).  usage: lat_threshold.py [config]"""
+"""Kernel time of mid-sized batches with the default slot policy against half / three quarters of the batch in slots.
+(Written when the kernel still had a latency mode -- one wave per query with a next-top prefetch, the default whenever
+the batch fit the resident slots: profiles/r2_lat_threshold.md.  The prefetch is gone; scripts/slot_fraction_sweep.py
+is the current tool.)  usage: lat_threshold.py [config]"""
 import json, os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
