@@ -471,7 +471,7 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     uint32_t wpc = h->waves_per_cu;
     if (!h->waves_from_env) {
         // registers (launch bounds of the instantiation) and LDS (160 KB per CU) both cap the resident waves
-        wpc = 4 * (uint32_t)search_waves_per_simd(search_static_d(h->L.D) ? (int)h->L.D : 0);
+        wpc = 4 * (uint32_t)search_waves_per_simd(search_static_d(h->L.D) ? (int)h->L.D : 0, (int)h->bits);
         const size_t lds_wave = search_lds_bytes(h->L.D, h->L.PW, k);
         wpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(wpc, (160u * 1024u) / lds_wave));
     }

@@ -452,9 +452,9 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512 or D*4] (popped vertex's vector, LDS-DMA target) |
-// pf[256] (prefetch sink, latency mode) | exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsTail = 256 + 128 + 64 + 128 + 16;      // (spare) | exact | list | slack | ratio
+constexpr uint32_t kLdsTail = 128 + 64 + 128 + 16;            // exact | list | slack | ratio
 // vec[] holds the popped vertex' whole vector in the instantiations with a compile-time D (LDS-DMA target)
 __host__ __device__ inline uint32_t search_vec_bytes(uint32_t D, bool static_d) { return static_d ? D * 4 : 512; }
 __host__ __device__ inline bool search_static_d(uint32_t D) { return D == 128 || D == 1024; }
@@ -493,11 +493,15 @@ __device__ __forceinline__ void lds_dma16(const void* g, uint32_t lds_off) {
 #ifndef CPH_SEARCH_WAVES_PER_SIMD_1024
 #define CPH_SEARCH_WAVES_PER_SIMD_1024 2
 #endif
-__host__ __device__ constexpr int search_waves_per_simd(int sd) {
-    return sd == 128 ? CPH_SEARCH_WAVES_PER_SIMD_128 : (sd == 1024 ? CPH_SEARCH_WAVES_PER_SIMD_1024 : CPH_SEARCH_WAVES_PER_SIMD);
+#ifndef CPH_SEARCH_WAVES_PER_SIMD_128_NARROW
+#define CPH_SEARCH_WAVES_PER_SIMD_128_NARROW CPH_SEARCH_WAVES_PER_SIMD_128
+#endif
+__host__ __device__ constexpr int search_waves_per_simd(int sd, int bw) {
+    return sd == 128 ? (bw <= 2 ? CPH_SEARCH_WAVES_PER_SIMD_128_NARROW : CPH_SEARCH_WAVES_PER_SIMD_128)
+                     : (sd == 1024 ? CPH_SEARCH_WAVES_PER_SIMD_1024 : CPH_SEARCH_WAVES_PER_SIMD);
 }
 template <int BW, int SD>
-__global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(SearchArgs a) {
+__global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kernel(SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const int li = lane & 31;
@@ -509,10 +513,10 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD)) void search_kernel(S
     unsigned char* fixed = smem + (size_t)PW * 16 + (size_t)D * 4;
     float* s_vec = reinterpret_cast<float*>(fixed);
     constexpr uint32_t vsz = SD >= 128 ? (uint32_t)SD * 4u : 512u;
-    float* s_exact = reinterpret_cast<float*>(fixed + vsz + 256);
-    uint8_t* s_list = fixed + vsz + 384;
-    float* s_slack = reinterpret_cast<float*>(fixed + vsz + 448);
-    double* s_ratio = reinterpret_cast<double*>(fixed + vsz + 576);   // [2]
+    float* s_exact = reinterpret_cast<float*>(fixed + vsz);
+    uint8_t* s_list = fixed + vsz + 128;
+    float* s_slack = reinterpret_cast<float*>(fixed + vsz + 192);
+    double* s_ratio = reinterpret_cast<double*>(fixed + vsz + 320);   // [2]
     Result* nn = reinterpret_cast<Result*>(fixed + vsz + kLdsTail);
     NnLds nnw;
     nnw.l = (lds_u32x2*)(fixed + vsz + kLdsTail);
