@@ -1,6 +1,8 @@
 // builder_pipeline.h — finalize(): the construction pipeline of builder.h, stage by stage, and the
 // calibration that follows it.  See builder.h for the design and the reference citations.
 #pragma once
+#include <exception>
+#include <thread>
 #include <type_traits>
 #include "builder.h"
 
@@ -110,6 +112,19 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
             if (entry_old == kInvalidNode || lv > max_level) { max_level = lv; entry_old = (uint32_t)i; }
         }
     }
+
+    // ---- upper layers: concurrent incremental insertion on the host (5 % of the vertices).  They need the vectors and
+    // the levels only, so the host threads build them while the GPU computes the kNN lists below ------------------
+    UpperLayers ul(vecs, dim, n, levels, max_level, entry_old, M_UPPER, R);
+    struct Background {                      // joins on every path out of this function
+        std::thread th;
+        std::exception_ptr err;
+        ~Background() { if (th.joinable()) th.join(); }
+        void wait() { if (th.joinable()) th.join(); if (err) std::rethrow_exception(err); }
+    } upper_job;
+    upper_job.th = std::thread([&ul, &upper_job] {
+        try { ul.build(); } catch (...) { upper_job.err = std::current_exception(); }
+    });
 
     // ---- exact 32-NN lists on the matrix cores ----------------------------------------------------------
     DevBuf<uint32_t> d_knn(n * kKnnK);
@@ -278,14 +293,13 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
     }
     tm.lap("gather + edge / own codes");
 
-    // ---- upper layers: concurrent incremental insertion on the host (5 % of the vertices) ----------------------
+    // ---- upper layers: started before the kNN (above) --------------------------------------------------------------
     std::vector<int32_t> levels_new(n);
     for (size_t nw = 0; nw < n; ++nw) levels_new[nw] = levels[new_to_old[nw]];
-    UpperLayers ul(vecs, dim, n, levels, max_level, entry_old, M_UPPER, R);
-    ul.build();
+    upper_job.wait();
     std::vector<std::vector<UpperEdge>> upper = ul.export_layers(old_to_new);
     const float upper_tau = ul.tau, upper_alpha = ul.alpha;
-    tm.lap("upper layers (host, concurrent)");
+    tm.lap("upper layers (host threads, built behind the kNN): wait + export");
 
     // ---- host side: vectors, norms, own-code headers (the reference-layout block image waits for save()) ----------
     hi.raw.resize(n * D);
