@@ -81,23 +81,35 @@ class CPIndex:
         import torch
         if queries.dim() != 2 or queries.shape[1] != self._dim or queries.dtype != torch.float32:
             raise ValueError("queries must be a (n, dim) array")
-        queries = queries.contiguous()
         n, k = queries.shape[0], int(k)
         if not queries.is_cuda or queries.device.index != self._device:
             raise ValueError("queries must live on this index' device")
+        fresh = []                       # tensors allocated here, on torch's current stream
+        if not queries.is_contiguous():
+            queries = queries.contiguous()
+            fresh.append(queries)
         if out is None:
             ids = torch.empty((n, k), dtype=torch.int64, device=queries.device)
             dist = torch.empty((n, k), dtype=torch.float32, device=queries.device)
+            fresh += [ids, dist]
         else:
             ids, dist = out
             for t, dt in ((ids, torch.int64), (dist, torch.float32)):
                 if (tuple(t.shape) != (n, k) or t.dtype != dt or t.device != queries.device
                         or not t.is_contiguous()):
                     raise ValueError("out must be contiguous (n, k) int64 / float32 tensors on the queries' device")
+        cur = torch.cuda.current_stream(queries.device)
         if stream is None:
-            st = torch.cuda.current_stream(queries.device).cuda_stream
+            st = cur.cuda_stream
         else:
             st = getattr(stream, "cuda_stream", stream)
+            if fresh and st != cur.cuda_stream:
+                # The copy / the allocations above belong to the current stream: the search stream has to run after
+                # them, and the caching allocator must not hand the blocks out again while the search still uses them.
+                ext = stream if isinstance(stream, torch.cuda.Stream) else torch.cuda.ExternalStream(st, device=queries.device)
+                ext.wait_stream(cur)
+                for t in fresh:
+                    t.record_stream(ext)
         _lib.check(_lib.lib().cph_search_batch_device(self._h, queries.data_ptr(), n, k, ids.data_ptr(),
                                                       dist.data_ptr(), C.c_void_p(st)))
         return ids, dist

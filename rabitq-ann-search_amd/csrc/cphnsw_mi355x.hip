@@ -25,6 +25,7 @@
 #include "device_stream.h"
 #include "device_heap_test.h"
 #include "host_index.h"
+#include "host_parallel.h"
 #include "native_file.h"
 #include "builder_pipeline.h"
 
@@ -63,21 +64,6 @@ size_t next_pow2(size_t n) {
     return p;
 }
 
-void parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
-    // at most 64 host threads per process: eight ranks share one node (one process per GPU)
-    unsigned hw = std::min(64u, std::thread::hardware_concurrency());
-    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 4, n / std::max<size_t>(min_chunk, 1)));
-    if (nt <= 1) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    size_t per = (n + nt - 1) / nt;
-    for (size_t t = 0; t < nt; ++t) {
-        size_t lo = t * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        th.emplace_back([=, &fn] { fn(lo, hi); });
-    }
-    for (auto& x : th) x.join();
-}
-
 // kernel dispatch over (bits, static D): D == 128 and D == 1024 (the BASELINE shapes) get instantiations with a
 // compile-time D -- every code load of a block in flight at once, the vertex vector through LDS-DMA
 #define CPH_LAUNCH_BITS(KERNEL, bits, SDV, grid, block, lds, st, args)                            \
@@ -111,12 +97,12 @@ struct BatchSet {
     unsigned long long* pin_stats = nullptr;   // pinned host copy, written at the end of every batch
     // per-slot scratch (estimated-set bitmap, beam spill area, id log), `cap` entries per slot
     DevBuf<uint32_t> d_bitmaps, d_logids;
-    DevBuf<uint4> d_beam;
+    DevBuf<uint32_t> d_beam;
     uint32_t slots = 0;
     uint64_t cap = 0;
     // full-capacity (n + 1) scratch of the overflow re-run launch
     DevBuf<uint32_t> r_bitmaps, r_logids;
-    DevBuf<uint4> r_beam;
+    DevBuf<uint32_t> r_beam;
     uint32_t r_slots = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     bool used = false;        // a batch has been enqueued on this set (ev_done is meaningful)
@@ -386,7 +372,7 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
         s.d_bitmaps.alloc((size_t)slots * bm_words);
         HIP_CHECK(hipMemsetAsync(s.d_bitmaps.p, 0, (size_t)slots * bm_words * 4, st));
         s.d_logids.alloc((size_t)slots * cap);
-        s.d_beam.alloc((size_t)slots * cap);
+        s.d_beam.alloc((size_t)slots * beam_slot_dwords(cap));
         s.slots = slots;
         s.cap = cap;
     }
@@ -394,12 +380,12 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
     if (cap < n + 1 && s.r_slots == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per = (n + 1) * 20 + bm_words * 4;
+        const uint64_t per = (n + 1) * 4 + beam_slot_dwords(n + 1) * 4 + bm_words * 4;
         const uint32_t rs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (uint64_t)(free_b * 0.25) / per));
         s.r_bitmaps.alloc((size_t)rs * bm_words);
         HIP_CHECK(hipMemsetAsync(s.r_bitmaps.p, 0, (size_t)rs * bm_words * 4, st));
         s.r_logids.alloc((size_t)rs * (n + 1));
-        s.r_beam.alloc((size_t)rs * (n + 1));
+        s.r_beam.alloc((size_t)rs * beam_slot_dwords(n + 1));
         s.r_slots = rs;
     }
 }
@@ -498,10 +484,11 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         // budget: at most 30% of what is free (plus what this set already holds) -- there are two sets
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t held = (uint64_t)s.slots * (s.cap * 20 + bm_bytes);
+        auto slot_bytes = [&](uint64_t c) { return c * 4 + (uint64_t)beam_slot_dwords(c) * 4 + bm_bytes; };   // id log + beam spill + bitmap
+        const uint64_t held = (uint64_t)s.slots * slot_bytes(s.cap);
         const uint64_t budget = (uint64_t)((free_b + held) * 0.3);
-        while (slots > 64 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) slots /= 2;
-        while (cap > 4096 && (uint64_t)slots * (cap * 20 + bm_bytes) > budget) cap /= 2;
+        while (slots > 64 && (uint64_t)slots * slot_bytes(cap) > budget) slots /= 2;
+        while (cap > 4096 && (uint64_t)slots * slot_bytes(cap) > budget) cap /= 2;
     }
     ensure_scratch(h, s, slots, cap, st);
     slots = std::min(slots, s.slots);
@@ -592,11 +579,28 @@ int cph_destroy(cph_index* h) {
     });
 }
 
+// Called once the new host-side index has been read and validated: from here until the end of a load the handle is
+// not searchable, so a failed device allocation or copy leaves it unfinalized (an error on the next search) instead of
+// finalized over null or stale device pointers.
+static void begin_device_swap(cph_index* h) {
+    h->use_device();
+    quiesce(h);
+    h->finalized = false;
+    for (auto& s : h->sets) release_scratch(s);
+    h->last_search = -1;
+}
+
 int cph_load(cph_index* h, const char* path) {
     return guarded([&] {
         if (!h || !path) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
-        h->host.load(path, h->D, h->bits, h->dim);  // commits only on success
+        HostIndex t;
+        t.load(path, h->D, h->bits, h->dim);        // a file that fails to parse leaves the handle as it was
+        begin_device_swap(h);
+        h->host = std::move(t);
+        h->needs_build = false;                       // api/hnsw_index.hpp:442
+        std::vector<float>().swap(h->pending);
+        h->pending_n = 0;
         h->native_map.reset();
         h->own_view = nullptr;
         std::vector<uint8_t>().swap(h->own_store);
@@ -641,12 +645,14 @@ int cph_load_native(cph_index* h, const char* path) {
     return guarded([&] {
         if (!h || !path) throw InvalidArg("null argument");
         std::lock_guard<std::mutex> lk(h->mu);
-        h->use_device();
-        quiesce(h);
         HostIndex t;
         NativeMapping map;
-        const NativeHeader nh = read_native(path, h->D, h->bits, h->dim, t, map);   // commits only on success
+        const NativeHeader nh = read_native(path, h->D, h->bits, h->dim, t, map);   // validates everything it maps
+        begin_device_swap(h);
         h->host = std::move(t);
+        h->needs_build = false;
+        std::vector<float>().swap(h->pending);
+        h->pending_n = 0;
         h->native_map = std::move(map);
         const uint8_t* base = static_cast<const uint8_t*>(h->native_map.base);
         std::vector<uint8_t>().swap(h->own_store);
@@ -773,7 +779,7 @@ int cph_debug_heap_ops(int device, const uint8_t* ops, uint64_t n_ops, const flo
         DevBuf<uint8_t> d_ops(n_ops);
         DevBuf<float> d_keys(std::max<uint64_t>(1, n_push)), d_ok(std::max<uint64_t>(1, n_push));
         DevBuf<uint32_t> d_ids(std::max<uint64_t>(1, n_push)), d_oi(std::max<uint64_t>(1, n_push)), d_sz(1);
-        DevBuf<uint4> d_spill(std::max<uint64_t>(1, n_push) + 64);
+        DevBuf<uint32_t> d_spill(beam_slot_dwords(std::max<uint64_t>(1, n_push) + 64));
         HIP_CHECK(hipMemcpy(d_ops.p, ops, n_ops, hipMemcpyHostToDevice));
         if (n_push) {
             HIP_CHECK(hipMemcpy(d_keys.p, keys, n_push * 4, hipMemcpyHostToDevice));
@@ -869,6 +875,10 @@ int cph_last_search_stats(cph_index* h, uint64_t out[12]) {
         out[9] = s.cap;
 #ifdef CPH_PHASE_TIMERS
         fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
+                s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);
+#endif
+#ifdef CPH_TRAFFIC_STATS
+        fprintf(stderr, "[traffic] hybrid_pops=%llu windows=%llu hybrid_pushes=%llu hbm_appends=%llu probe_lines=%llu sum_beam_at_pop=%llu max_beam=%llu pops_beyond_8191=%llu\n",
                 s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);
 #endif
     });

@@ -16,7 +16,7 @@ struct HeapTestArgs {
     const float* keys;       // [pushes]
     const uint32_t* ids;     // [pushes]
     uint32_t n_ops;
-    uint4* spill;            // [cap] HBM part of the heap (index = heap index)
+    uint32_t* spill;         // [beam_slot_dwords(cap)] HBM part of the heap (beam_off)
     float* out_keys;         // [final size]
     uint32_t* out_ids;
     uint32_t* out_size;

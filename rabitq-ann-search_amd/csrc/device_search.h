@@ -56,7 +56,7 @@ struct SearchArgs {
     uint64_t cap;           // per-slot log/heap capacity
     uint64_t bm_words;      // per-slot bitmap words
     uint32_t* bitmaps;
-    uint4* beam;            // beam heap beyond the LDS-resident top levels (index = heap index)
+    uint32_t* beam;         // beam heap beyond the LDS-resident top levels: beam_slot_dwords(cap) per slot (beam_off)
     uint32_t* log_ids;      // every newly estimated id, in discovery order (for un-marking)
     // outputs
     int64_t* out_ids;       // [nq][k]
@@ -136,10 +136,31 @@ __device__ __forceinline__ void nn_sort(Result* h, uint32_t size) {  // std::sor
 }
 
 // Beam: std::priority_queue<BeamEntry, vector, greater> — a heap whose comparator is
-// "a.est > b.est" (rabitq_search.hpp:57,79-80).  Structure-of-arrays {est, lower, id}; heap
-// indices below kBeamLds live in LDS (the levels every pop walks through), deeper ones in the
-// slot's global scratch.  Element movement is exactly libstdc++'s, wherever an index lives.
-constexpr uint32_t kBeamLds = 255;  // 8 full levels, 16 B per entry
+// "a.est > b.est" (rabitq_search.hpp:57,79-80).  The LOGICAL heap -- which entry sits at which heap index after
+// every operation -- is libstdc++'s, move for move; where a heap index lives physically is ours to choose:
+//
+//   heap indices 0..254      (levels 0..7)   LDS, 16 B per entry: the levels every pop walks through
+//   heap indices 255..8190   (levels 8..12)  HBM, PAGES: the 62 descendants of one level-7 node over the next five
+//                                            levels are one contiguous block of 64 x 12 B {est, lower, id} (six
+//                                            128-byte lines; entry r = the node's 1-based index inside that subtree,
+//                                            entries 0 and 1 unused) -- a B-heap page.  A pop's window (the 62
+//                                            candidates of its next five levels) is one coalesced 744-byte read that
+//                                            brings the WHOLE entries, so the moves along the path need no second
+//                                            round trip; a push finds all its ancestors of levels 8..11 in the first
+//                                            three lines of one page
+//   heap indices >= 8191     (levels 13+)    HBM, 12 B per entry in heap order behind the 128 pages
+//
+// (Round 2 kept the HBM part as 16-byte entries in heap order: a window's 62 keys were 248 useful bytes spread over
+// nine to twelve lines in five places, and the moves re-read the path's entries in a second, dependent round trip.)
+constexpr uint32_t kBeamLds = 255;                    // 8 full levels, 16 B per entry
+constexpr uint32_t kBeamPaged = 8191;                 // heap indices below this and >= kBeamLds live in pages
+constexpr uint32_t kPageDwords = 192;                 // 64 entries x 3 dwords
+constexpr uint32_t kBeamTail = 128 * kPageDwords;     // dword offset of heap index kBeamPaged
+// dwords of one slot's spill area for a beam of at most `cap` entries (a multiple of 32: slots start on a line)
+__host__ __device__ inline size_t beam_slot_dwords(uint64_t cap) {
+    const size_t d = kBeamTail + 3 * (size_t)(cap > kBeamPaged ? cap - kBeamPaged : 0) + 4;
+    return (d + 31) & ~(size_t)31;
+}
 
 struct BeamEntry {
     float est, lower;
@@ -149,13 +170,23 @@ struct BeamEntry {
 // The LDS part is addressed through address-space-3 pointers so that every access is a ds_*
 // instruction (a generic pointer would make them flat_* accesses, which also wait on vmcnt).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) float lds_f32;
+
+// dword offset of heap index i >= kBeamLds inside the slot's spill area
+__device__ __forceinline__ uint32_t beam_spill_off(uint32_t i) {
+    const uint32_t hp = i + 1;
+    const uint32_t l = (31u - (uint32_t)__builtin_clz(hp)) - 7u;              // levels below the LDS part: 1..5 in the pages
+    const uint32_t r = (hp & ((1u << (l & 7u)) - 1u)) | (1u << (l & 7u));     // index inside the level-7 node's subtree
+    const uint32_t paged = ((hp >> (l & 7u)) - 128u) * kPageDwords + 3u * r;
+    return hp < kBeamPaged + 1 ? paged : kBeamTail + 3u * (hp - (kBeamPaged + 1));
+}
 
 struct Beam {
     typedef uint4 E;
     lds_u32x4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
-    uint4* g;       // global, [cap], indexed by heap index
+    uint32_t* g;    // global, the slot's spill area (beam_off)
     // the heap's comparator (std::greater on est: a min-heap) and the key of an entry
     static __device__ __forceinline__ bool before(float a, float b) { return a > b; }
     static __device__ __forceinline__ float key_of(uint4 e) { return __uint_as_float(e.x); }
@@ -171,17 +202,27 @@ struct Beam {
     __device__ __forceinline__ float lds_key(uint32_t i) const {
         return reinterpret_cast<lds_f32*>(l)[4 * i];
     }
+    // one 12-byte entry of the spill area (dword offset)
+    __device__ __forceinline__ uint4 gload(uint32_t off) const {
+        const u32x3 t = *reinterpret_cast<const u32x3 __attribute__((aligned(4)))*>(g + off);
+        return make_uint4(t.x, t.y, t.z, 0u);
+    }
+    __device__ __forceinline__ void gstore(uint32_t off, uint4 v) const {
+        u32x3 t;
+        t.x = v.x; t.y = v.y; t.z = v.z;
+        *reinterpret_cast<u32x3 __attribute__((aligned(4)))*>(g + off) = t;
+    }
     __device__ __forceinline__ uint4 raw(uint32_t i) const {
         uint4 v;
-        if (i < kBeamLds) v = lds(i); else v = g[i];
+        if (i < kBeamLds) v = lds(i); else v = gload(beam_spill_off(i));
         return v;
     }
     __device__ __forceinline__ void put(uint32_t i, uint4 v) const {
-        if (i < kBeamLds) lds_put(i, v); else g[i] = v;
+        if (i < kBeamLds) lds_put(i, v); else gstore(beam_spill_off(i), v);
     }
     __device__ __forceinline__ float raw_key(uint32_t i) const {
         float k;
-        if (i < kBeamLds) k = lds_key(i); else k = reinterpret_cast<const float*>(g)[4 * (size_t)i];
+        if (i < kBeamLds) k = lds_key(i); else k = __uint_as_float(g[beam_spill_off(i)]);
         return k;
     }
     __device__ __forceinline__ BeamEntry get(uint32_t i) const {
@@ -324,19 +365,19 @@ __device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typena
 
 // ---- the same two operations for a beam that has outgrown its LDS levels (entries kBeamLds.. live in HBM) --------
 // A lane-0 sift is one dependent HBM round trip per heap level below the LDS part -- 5 to 10 of them per pop once a beam
-// holds thousands of entries (the recall >= 0.95 workload: 63 % of the kernel's time went there).  The moves stay
-// libstdc++'s; the schedule becomes: (1) the 7 LDS levels are walked on ballot masks as in heap_pop_wave; (2) below them
-// the wave reads a WINDOW of the subtree under the current node -- its 62 descendants of the next five levels, one key
-// per lane, one round trip -- decides every "which child moves up" of the window with one ballot and walks five levels
-// on the mask; (3) the path is then a bit string, so every lane knows its pair of positions and the entries move with
-// one parallel read (lines the window just brought into L2) and one parallel write.  Two to four round trips in
-// place of one per level: 334 -> 216 ms per 10,000 queries of that workload.  (Also tried: six-level windows holding
-// whole entries, two per lane, with the path's lanes storing their entries one level up and no re-read -- one round
-// trip per pop, but 12 more live registers where the block's loads are in flight: spills, 251 ms there and the
-// D = 128 / 4-bit kernel 12 % slower.)
+// holds thousands of entries (the recall >= 0.95 workload keeps ~5,000 on average).  The moves stay libstdc++'s; the
+// schedule becomes: (1) the 7 LDS levels are walked on ballot masks as in heap_pop_wave; (2) below them the wave reads
+// the PAGE of the level-7 node it arrived at -- the 62 descendants of the next five levels, one whole entry per lane,
+// one coalesced read -- decides every "which child moves up" of the window with one ballot and walks five levels on
+// the mask; (3) the path is then a bit string, every lane knows its pair of positions, and the entries of levels 8..12
+// that move are already in registers (handed to the path's lanes by ds_bpermute): one HBM round trip per pop, followed
+// only by the stores.  Beams beyond 8,191 entries (6 % of that workload's pops) continue with windows of keys over the
+// heap-ordered tail and fetch those levels' path entries in a second round trip.
+// History: lane-0 sifts 334 ms per 10,000 queries of that workload; windows of keys over 16-byte entries in heap
+// order + a dependent read of the path (round 2) 216 ms; pages (round 3): see DESIGN.md section 6.
 __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, int lane) {
     const uint32_t len = size - 1;                 // >= kBeamLds: the last element lives in HBM
-    const uint4 v = h.g[len];                      // the value __adjust_heap re-inserts (same address in every lane)
+    const uint4 v = h.gload(beam_spill_off(len));        // the value __adjust_heap re-inserts (same address in every lane)
     // LDS levels 0..6: nodes 0..126, both children always inside the LDS part
     const bool b0 = Beam::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1));
     const unsigned long long m0 = __ballot(b0);
@@ -350,19 +391,15 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
         const unsigned long long m = hole < 64 ? m0 : m1;
         hp = 2 * hp + 1 - ((uint32_t)(m >> (hole & 63)) & 1u);
     }
-    // HBM levels: windows of five levels under node hp - 1
-    const float* gk = reinterpret_cast<const float*>(h.g);
-    for (;;) {
-        if (2 * hp >= len) break;                  // no right child: __adjust_heap's loop ends here
-        const uint32_t r = (uint32_t)lane + 2;     // relative node, 1-based, root = 1: lanes 0..61 hold 2..63
-        const uint32_t dr = 31u - (uint32_t)__builtin_clz(r);
-        const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
-        float key = 0.0f;
-        if (lane < 62 && idx < len) key = gk[4 * (size_t)idx];
+    // relative node of this lane inside a five-level window: 1-based, the window's root = 1, lanes 0..61 hold 2..63
+    const uint32_t r = (uint32_t)lane + 2;
+    const uint32_t dr = 31u - (uint32_t)__builtin_clz(r);
+    // one window: E2 = pairs of children that both exist, M = "the left child moves up"; walks up to five levels
+    auto walk = [&](float key, uint32_t idx) {
         const float key_r = __shfl_down(key, 1);   // even lanes hold left children, their right siblings sit one lane up
         const bool both = (lane & 1) == 0 && lane < 62 && idx + 1 < len;
         const unsigned long long E2 = __ballot(both);
-        const unsigned long long M = __ballot(both && Beam::before(key_r, key));   // true: the left child moves up
+        const unsigned long long M = __ballot(both && Beam::before(key_r, key));
         uint32_t P = 1, steps = 0;
         while (steps < 5) {
             const uint32_t bit = 2 * P - 2;        // the pair under relative node P sits in lanes 2P-2, 2P-1
@@ -372,21 +409,46 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
         }
         hp = (hp << steps) | (P & ((1u << steps) - 1u));
         d += steps;
-        if (steps < 5) break;
+        return steps;
+    };
+    // levels 8..12: the page of the level-7 node (read whenever that node has a child at all, so that every path
+    // entry of these levels -- including a last left-only child -- is in some lane's registers)
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t steps = 0;
+    if (2 * hp - 1 < len) {
+        const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
+        if (lane < 62 && idx < len) w = h.gload((hp - 128u) * kPageDwords + 3u * r);
+        steps = walk(__uint_as_float(w.x), idx);
+    }
+    // levels 13+: windows of keys over the heap-ordered tail
+    while (steps == 5 && 2 * hp < len) {
+        const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
+        float key = 0.0f;
+        if (lane < 62 && idx < len) key = __uint_as_float(h.g[beam_spill_off(idx)]);
+        steps = walk(key, idx);
     }
     if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
         hp = 2 * hp;
         ++d;
     }
-    // the moves (heap_pop_wave's second half on the hybrid accessors; d <= 31 lanes take part)
+    // the moves (heap_pop_wave's second half; d <= 31 lanes take part).  Lane t moves the entry at p_(t+1) to p_t.
     const uint32_t hole = hp - 1;
     const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
     const uint32_t my_dst = (hp >> (d - t)) - 1;
-    const uint32_t my_src = (hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u))) - 1;
+    const uint32_t src_hp = hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u));    // p_(t+1) + 1, level t + 1
+    const uint32_t my_src = src_hp - 1;
+    // sources on levels 8..12 come out of the window lane that read them: relative node -> lane r - 2
+    const bool from_page = (uint32_t)lane < d && t >= 7 && t <= 11;
+    const uint32_t lvl = from_page ? t - 6u : 1u;
+    const int page_lane = (int)(((src_hp & ((1u << lvl) - 1u)) | (1u << lvl)) - 2u);
+    const uint4 pw = make_uint4((uint32_t)__shfl((int)w.x, page_lane), (uint32_t)__shfl((int)w.y, page_lane),
+                                (uint32_t)__shfl((int)w.z, page_lane), 0u);
     uint4 e = v;
     bool c = false;
     if ((uint32_t)lane < d) {
-        e = h.raw(my_src);
+        if (t < 7) e = h.lds(my_src);
+        else if (t <= 11) e = pw;
+        else e = h.gload(beam_spill_off(my_src));
         c = Beam::before(Beam::key_of(e), Beam::key_of(v));
     }
     const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
@@ -533,7 +595,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
     uint32_t* logi = CPH_COLD(log_ids) + (size_t)slot * a.cap;
     Beam heap;
     heap.l = s_beam;
-    heap.g = CPH_COLD(beam) + (size_t)slot * a.cap;
+    heap.g = CPH_COLD(beam) + (size_t)slot * beam_slot_dwords(a.cap);
     const float FMAX = 3.402823466e+38f;
     if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
@@ -595,6 +657,10 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
         int slack_batch = 0;
         bool overflow = false;
         uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0, st_allseen = 0;
+#ifdef CPH_TRAFFIC_STATS
+        // diagnostic build only: what the spilled beam and the estimated-set probe touch (stats[8..15])
+        unsigned long long trf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #ifdef CPH_PHASE_TIMERS
         unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tlast = clock64();
@@ -628,6 +694,12 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             float worst_pop;   // result-heap threshold as read here (wave-uniform)
             // std::pop_heap of the beam (whole wave while it lives in LDS, lane 0 once it has spilled)
             auto pop_beam = [&](uint32_t size) {
+#ifdef CPH_TRAFFIC_STATS
+                trf[5] += size;
+                if (size > trf[6]) trf[6] = size;
+                if (size > kBeamLds) { trf[0]++; uint32_t lv = 31u - (uint32_t)__builtin_clz(size); trf[1] += (lv - 7 + 4) / 5; }
+                if (size > 8191) trf[7]++;
+#endif
                 if (size > 1) {
                     if (size <= kBeamLds) heap_pop_wave(heap, size, lane);
                     else beam_pop_hybrid(heap, size, lane);
@@ -661,7 +733,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // of cycles old, its marking atomics return nothing).  Saying so with a wait the compiler
             // can see keeps it from protecting registers it believes some path around the loop left
             // a load pending on -- such a wait, between the loads below, would be a real one.
+#ifndef CPH_NO_LOOPHEAD_WAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
             // The popped vertex's own vector goes straight to LDS (LDS-DMA, 16 B per lane, one
             // instruction for the 512 B; the strided per-chain reads then come from LDS).  It is
             // issued FIRST: loads retire in order, so retiring the other loads below also covers it.
@@ -683,6 +757,18 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // above already have; its three dependent LDS round trips and its scalar path walk (a fifth of an
             // expansion's time when it ran in front of the loads) now hide behind the block's memory latency.
             // LDS and scalar work only (lgkmcnt), so no wait on the loads (vmcnt) is forced here.
+            // Spilled beams: the pushes at the end of this expansion will compare against the ancestors of the leaf the
+            // pop is about to free (heap index beam_size - 1).  Those of them that live in HBM are touched now, one per
+            // lane, in the same round trip as the block: the pushes' own reads then hit in L2 instead of being another
+            // dependent trip to HBM.  (Always issued -- a load that is only sometimes in flight would turn the compiler's
+            // later counted waits into vmcnt(0) -- lanes with nothing to touch read the slot's first word; the value is
+            // consumed, unused, where the block's loads are retired anyway.)
+            uint32_t touch;
+            {
+                const uint32_t tp = (beam_size >> ((uint32_t)lane + 1u)) - 1u;       // ancestor t = lane + 1 of heap index beam_size - 1
+                const bool on = beam_size > kBeamLds && lane < 31 && (beam_size >> ((uint32_t)lane + 1u)) > kBeamLds;
+                touch = heap.g[on ? beam_spill_off(tp) : 0u];
+            }
             pop_beam(beam_size);
             --beam_size;
             __builtin_amdgcn_sched_barrier(0);
@@ -697,7 +783,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             float dot_generic = 0.0f;
             if constexpr (SD < 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
             bl.retire();
-            asm volatile("" : "+v"(cur_norm), "+v"(nid));
+            asm volatile("" : "+v"(cur_norm), "+v"(nid) : "v"(touch));
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
             const bool active = lane < 32 && valid;
             // The probe is a plain (device-coherent: it must not be served from this CU's L1, which
@@ -708,6 +794,18 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             const uint32_t my_bit = 1u << (nid & 31);
             if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef CPH_TRAFFIC_STATS
+            {   // distinct 128-byte lines of the bitmap this probe touches
+                const uint32_t line = nid >> 10;
+                bool first = active;
+                for (int j = 0; j < 31; ++j) {
+                    const uint32_t oj = __shfl(line, j);
+                    const bool aj = __shfl((int)active, j) != 0;
+                    if (aj && lane > j && oj == line) first = false;
+                }
+                trf[4] += __popcll(__ballot(first));
+            }
+#endif
 
             // ---- exact distance of the popped node; nn.push (:130-133) ----------------
             float exact_dist;
@@ -849,6 +947,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     bool stay = true;
                     if (p && pos > 0) stay = !((in_lds ? heap.lds_key((pos - 1) >> 1) : heap.raw_key((pos - 1) >> 1)) > est);
                     if (__all(stay)) {
+#ifdef CPH_TRAFFIC_STATS
+                        if (!in_lds) trf[3]++;
+#endif
                         const uint4 ent = make_uint4(__float_as_uint(est), __float_as_uint(lower), nid, 0u);
                         if (p) { if (in_lds) heap.lds_put(pos, ent); else heap.put(pos, ent); }
                         beam_size += np;
@@ -863,6 +964,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                         const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
                         const uint32_t e_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i);
                         const uint32_t lo_i = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i);
+#ifdef CPH_TRAFFIC_STATS
+                        if (beam_size >= kBeamLds) trf[2]++;
+#endif
                         if (beam_size < kBeamLds) heap_push_wave(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
                         else beam_push_hybrid(heap, beam_size, make_uint4(e_i, lo_i, id_i, 0u), lane);
                         ++beam_size;
@@ -921,6 +1025,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     }
                     if (bcast_u32(push ? 1u : 0u)) {
                         const uint4 ent = beam_pack(BeamEntry{key, lo, id_i});
+#ifdef CPH_TRAFFIC_STATS
+                        if (beam_size >= kBeamLds) trf[2]++;
+#endif
                         if (beam_size < kBeamLds) heap_push_wave(heap, beam_size, ent, lane);
                         else beam_push_hybrid(heap, beam_size, ent, lane);
                         ++beam_size;
@@ -967,6 +1074,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             atomicAdd(&stats[7], (unsigned long long)st_allseen);
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tph[i]);
+#endif
+#ifdef CPH_TRAFFIC_STATS
+            for (int i = 0; i < 8; ++i) { if (i == 6) atomicMax(&stats[8 + i], trf[i]); else atomicAdd(&stats[8 + i], trf[i]); }
 #endif
             if (overflow) {
                 atomicAdd(&stats[5], 1ull);

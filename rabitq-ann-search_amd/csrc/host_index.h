@@ -11,6 +11,8 @@
 // This file is compiled with -ffp-contract=off; each fused multiply-add is explicit and
 // sits where the compiled reference has one.
 #pragma once
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -119,6 +121,35 @@ inline void lut_to_qu(const uint8_t* lut, size_t D, uint8_t* qu) {
     for (size_t d = 0; d < D; ++d) qu[d] = lut[(d / 4) * 16 + (1u << (d % 4))];
 }
 
+// A file that appears under its final name only when it is complete: written as <path>.tmp.<pid>, flushed and closed
+// with the results checked, then renamed over the target.  A handle that serves an index out of a mapping of
+// `path` keeps its (old) inode; a failed or interrupted save leaves the previous file untouched.
+struct AtomicFile {
+    std::string path, tmp;
+    FILE* f = nullptr;
+    explicit AtomicFile(const std::string& p) : path(p), tmp(p + ".tmp." + std::to_string((long)getpid())) {
+        f = std::fopen(tmp.c_str(), "wb");
+        if (!f) throw std::runtime_error("Cannot open file for writing: " + path);
+    }
+    AtomicFile(const AtomicFile&) = delete;
+    AtomicFile& operator=(const AtomicFile&) = delete;
+    void write(const void* p, size_t b) {
+        if (b && std::fwrite(p, 1, b, f) != b) throw std::runtime_error("Write error: " + path);
+    }
+    void commit() {
+        const bool ok = std::fflush(f) == 0;
+        const bool closed = std::fclose(f) == 0;
+        f = nullptr;
+        if (!ok || !closed) throw std::runtime_error("Write error: " + path);
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("Cannot open file for writing: " + path);
+        tmp.clear();
+    }
+    ~AtomicFile() {
+        if (f) std::fclose(f);
+        if (!tmp.empty()) std::remove(tmp.c_str());
+    }
+};
+
 struct HostIndex {
     size_t D = 0, bw = 0, dim = 0, n = 0;
     int32_t max_level = 0;
@@ -204,6 +235,15 @@ struct HostIndex {
         rdn(t.calib, 248);
         rdn(t.profile, 72);
         const size_t n = t.n;
+        {   // the counts come from the file: check them against its size before anything is allocated from them
+            const long here = std::ftell(f);
+            std::fseek(f, 0, SEEK_END);
+            const long total = std::ftell(f);
+            std::fseek(f, here, SEEK_SET);
+            const unsigned __int128 need = (unsigned __int128)n * (8 + t.D * 4 + t.RL.vertex_bytes) + t.dim * 4 + 4;
+            if (here < 0 || total < here || need > (unsigned __int128)(total - here))
+                throw std::runtime_error("Read error or truncated file: " + path);
+        }
         t.centroid.resize(t.dim);  rdn(t.centroid.data(), t.dim * 4);
         t.levels.resize(n);        rdn(t.levels.data(), n * 4);
         t.norm_sq.resize(n);       rdn(t.norm_sq.data(), n * 4);
@@ -212,15 +252,18 @@ struct HostIndex {
         rdn(t.search_data.data(), t.search_data.size());
         uint32_t nl = 0;
         rdn(&nl, 4);
+        if (nl > 64) throw std::runtime_error("Corrupt index: too many upper layers");
         t.upper.resize(nl);
         for (uint32_t l = 0; l < nl; ++l) {
             uint32_t sz = 0;
             rdn(&sz, 4);
+            if (sz > n) throw std::runtime_error("Corrupt index: upper layer larger than the index");
             t.upper[l].resize(sz);
             for (uint32_t e = 0; e < sz; ++e) {
                 uint32_t cnt = 0;
                 rdn(&t.upper[l][e].node, 4);
                 rdn(&cnt, 4);
+                if (cnt > n) throw std::runtime_error("Corrupt index: upper-layer degree out of range");
                 t.upper[l][e].nbrs.resize(cnt);
                 rdn(t.upper[l][e].nbrs.data(), (size_t)cnt * 4);
             }
@@ -233,6 +276,7 @@ struct HostIndex {
     // The reference trusts the file; the GPU path must not chase an out-of-range id.
     void validate() {
         has_dup_neighbors = false;
+        if (n != 0 && entry != kInvalidNode && entry >= n) throw std::runtime_error("Corrupt index: entry point out of range");
         for (size_t v = 0; v < n; ++v) {
             const uint8_t* nb = &search_data[v * RL.vertex_bytes + RL.nb_off];
             uint32_t cnt = rd<uint32_t>(nb + RL.count);
@@ -254,12 +298,8 @@ struct HostIndex {
 
     // api/hnsw_index.hpp:217-303
     void save(const std::string& path) const {
-        FILE* f = std::fopen(path.c_str(), "wb");
-        if (!f) throw std::runtime_error("Cannot open file for writing: " + path);
-        struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
-        auto wr = [&](const void* p, size_t b) {
-            if (b && std::fwrite(p, 1, b, f) != b) throw std::runtime_error("Write error: " + path);
-        };
+        AtomicFile out(path);
+        auto wr = [&](const void* p, size_t b) { out.write(p, b); };
         const uint64_t magic = 0x57534E48504300ULL;
         const uint32_t version = 2, hD = (uint32_t)D, hR = 32, hBW = (uint32_t)bw, hdim = (uint32_t)dim;
         const uint64_t hn = n;
@@ -283,6 +323,7 @@ struct HostIndex {
                 wr(e.nbrs.data(), (size_t)cnt * 4);
             }
         }
+        out.commit();
     }
 
     const uint8_t* nb(size_t v) const { return &search_data[v * RL.vertex_bytes + RL.nb_off]; }

@@ -24,7 +24,10 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "host_index.h"
+#include "host_parallel.h"
 
 namespace cph {
 
@@ -97,13 +100,11 @@ inline void write_native(const std::string& path, const HostIndex& hi, uint32_t 
     h.raw_off = align_up(h.own_off + hi.n * own_stride, 4096);
     h.blocks_off = align_up(h.raw_off + hi.n * hi.D * 4, 4096);
     h.file_bytes = h.blocks_off + hi.n * (uint64_t)stride;
-    FILE* f = std::fopen(path.c_str(), "wb");
-    if (!f) throw std::runtime_error("Cannot open file for writing: " + path);
-    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
-    auto wr = [&](const void* p, size_t b) { if (b && std::fwrite(p, 1, b, f) != b) throw std::runtime_error("Write error: " + path); };
+    AtomicFile out(path);       // saving over the file this handle is mapped from keeps the old inode mapped
+    uint64_t pos = 0;
+    auto wr = [&](const void* p, size_t b) { out.write(p, b); pos += b; };
     auto pad_to = [&](uint64_t off) {
-        const long cur = std::ftell(f);
-        std::vector<uint8_t> z((size_t)(off - (uint64_t)cur), 0);
+        std::vector<uint8_t> z((size_t)(off - pos), 0);
         wr(z.data(), z.size());
     };
     wr(&h, sizeof(h));
@@ -114,6 +115,7 @@ inline void write_native(const std::string& path, const HostIndex& hi, uint32_t 
     wr(hi.vec(0), hi.n * hi.D * 4);
     pad_to(h.blocks_off);
     wr(blocks, hi.n * (uint64_t)stride);
+    out.commit();
 }
 
 // Maps the file and fills everything of `hi` except raw / search_data (raw_view points into the mapping).
@@ -138,8 +140,24 @@ inline NativeHeader read_native(const std::string& path, size_t expect_D, size_t
                                  std::to_string(h.bw) + ", expected D=" + std::to_string(expect_D) + " R=32 BW=" + std::to_string(expect_bw));
     if (h.dim != expect_dim)
         throw std::runtime_error("Index file dim=" + std::to_string(h.dim) + " mismatches Index dim=" + std::to_string(expect_dim));
-    if (h.file_bytes > m.bytes || h.stride != make_dev_layout(h.D, h.bw).stride)
-        throw std::runtime_error("Read error or truncated file: " + path);
+    // Nothing below trusts the header: every section must lie inside the mapping, in order and without overlap,
+    // with the strides this library computes itself (a wrong offset would otherwise be a SIGBUS in a memcpy, which
+    // no exception handler catches).
+    {
+        typedef unsigned __int128 u128;
+        const DevLayout DL = make_dev_layout(h.D, h.bw);
+        const RefLayout RLc = make_ref_layout(h.D, h.bw);
+        const bool ok = h.n >= 1 && h.n < 0xFFFFFFFFull && h.stride == DL.stride && h.own_stride == RLc.nb_off &&
+                        h.n_layers <= 64 &&
+                        (u128)sizeof(NativeHeader) + h.small_bytes <= h.own_off &&
+                        (u128)h.own_off + (u128)h.n * h.own_stride <= h.raw_off &&
+                        (u128)h.raw_off + (u128)h.n * h.D * 4 <= h.blocks_off &&
+                        (u128)h.blocks_off + (u128)h.n * h.stride == h.file_bytes && h.file_bytes <= m.bytes &&
+                        h.raw_off % 4 == 0 && h.blocks_off % 4 == 0 &&
+                        (u128)h.small_bytes >= (u128)320 + (u128)h.dim * 4 + (u128)h.n * 8;
+        if (!ok) throw std::runtime_error("Read error or truncated file: " + path);
+        if (h.entry != kInvalidNode && h.entry >= h.n) throw std::runtime_error("Corrupt index: entry point out of range");
+    }
     HostIndex t;
     t.D = h.D; t.bw = h.bw; t.dim = h.dim; t.n = h.n; t.max_level = h.max_level; t.entry = h.entry;
     t.upper_tau = h.upper_tau; t.upper_alpha = h.upper_alpha; t.mL = h.mL; t.seed = h.seed;
@@ -161,17 +179,48 @@ inline NativeHeader read_native(const std::string& path, size_t expect_D, size_t
     for (auto& layer : t.upper) {
         uint32_t sz = 0;
         get(&sz, 4);
+        if (sz > t.n) throw std::runtime_error("Corrupt index: upper layer larger than the index");
         layer.resize(sz);
         for (auto& e : layer) {
             uint32_t cnt = 0;
             get(&e.node, 4);
             get(&cnt, 4);
+            if ((size_t)cnt * 4 > (size_t)(end - p)) throw std::runtime_error("Read error or truncated file: " + path);
             e.nbrs.resize(cnt);
             get(e.nbrs.data(), (size_t)cnt * 4);
             if (e.node >= t.n) throw std::runtime_error("Corrupt index: upper-layer node out of range");
             for (uint32_t x : e.nbrs)
                 if (x >= t.n) throw std::runtime_error("Corrupt index: upper-layer neighbour out of range");
         }
+    }
+    // The device blocks are handed to the GPU as they are: a neighbour id the search kernel would chase must be a
+    // vertex (the v2 loader's validate() makes the same promise), unused slots must carry the invalid marker the
+    // kernels rely on instead of `count`, and the repeated-id flag is recomputed rather than believed.
+    {
+        const DevLayout DL = make_dev_layout(h.D, h.bw);
+        const uint8_t* blocks = static_cast<const uint8_t*>(base) + h.blocks_off;
+        std::atomic<int> bad{0}, dup{0};
+        parallel_for(t.n, 4096, [&](size_t lo, size_t hi_) {
+            int b = 0, d = 0;
+            for (size_t v = lo; v < hi_ && !b; ++v) {
+                const uint8_t* blk = blocks + v * (size_t)DL.stride;
+                uint32_t cnt, ids[32];
+                std::memcpy(&cnt, blk + DL.count_off, 4);
+                std::memcpy(ids, blk + DL.ids_off, 128);
+                if (cnt > 32) { b = 1; break; }
+                for (uint32_t i = 0; i < 32; ++i) {
+                    if (i < cnt) {
+                        if (ids[i] >= t.n) b = 2;
+                        for (uint32_t j = 0; j < i; ++j) d |= ids[j] == ids[i];
+                    } else if (ids[i] != kInvalidNode) b = 3;
+                }
+            }
+            if (b) bad.store(b);
+            if (d) dup.store(1);
+        });
+        if (bad.load() == 1) throw std::runtime_error("Corrupt index: neighbour count > 32");
+        if (bad.load()) throw std::runtime_error("Corrupt index: neighbour id out of range");
+        t.has_dup_neighbors = dup.load() != 0;
     }
     t.raw_view = reinterpret_cast<const float*>(static_cast<const uint8_t*>(base) + h.raw_off);
     t.rot.init(t.D, t.seed);

@@ -3,6 +3,8 @@ vectors and the oracle.  Bit-exact everywhere: integer sums, fp32 estimates and 
 (tolerance stated by north_star is 1e-4 relative — we hold 0 ulp), exact-L2 distances and
 the final ids/distances including duplicates and ties.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -471,6 +473,53 @@ def test_native_file_roundtrip(cph, gold, tmp_path, name, bits):
         ix3.load_native(fixture_path(name, bits))
     with pytest.raises(RuntimeError, match="mismatch"):
         cph.CPIndex(DATASETS[name]["dim"], 1 if bits != 1 else 2).load_native(pn)
+
+
+def test_native_file_save_over_its_own_mapping_and_rejects_corruption(cph, gold, tmp_path):
+    """load_native(p) serves vectors and own-code headers out of a mapping of p: save_native(p) and save(p) on the same
+    path must neither crash (a truncating open would SIGBUS the mapping) nor lose the file -- both writers go through a
+    temporary file and rename().  A truncated or corrupted native file is an error code, not a fault: the header's
+    offsets, the neighbour counts and the neighbour ids are all checked before anything reaches the GPU."""
+    name, bits = "g128", 4
+    ix = _load(cph, name, bits)
+    pn = str(tmp_path / "x.cphn")
+    ix.save_native(pn)
+    good = open(pn, "rb").read()
+    a = cph.CPIndex(DATASETS[name]["dim"], bits)
+    a.load_native(pn)
+    a.save_native(pn)                                  # over the file the handle is mapped from
+    assert open(pn, "rb").read() == good
+    Q = gold[f"Q/{name}"]
+    ids, d = a.search_batch(Q, 10)
+    assert np.array_equal(ids, gold[f"S/{name}/b{bits}/plain/k10/ids"]) and _beq(d, gold[f"S/{name}/b{bits}/plain/k10/d"])
+    assert _beq(a.get_vectors(), ix.get_vectors())     # still served from the (old) mapping
+    a.save(pn)                                         # a v2 file under the same name
+    assert open(pn, "rb").read() == open(fixture_path(name, bits), "rb").read()
+    assert _beq(a.get_vectors(), ix.get_vectors())
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+    # malformed native files: the handle stays searchable with what it had
+    import struct
+    n = DATASETS[name]["n"]
+    hdr_n, hdr_blocks = 24, 104                        # offsetof(NativeHeader, n / blocks_off)
+    blocks_off = struct.unpack_from("<Q", good, hdr_blocks)[0]
+    stride = struct.unpack_from("<I", good, 32)[0]
+    cases = {
+        "truncated": good[: len(good) // 2],
+        "header only": good[:120],
+        "n too large": good[:hdr_n] + struct.pack("<Q", n * 50) + good[hdr_n + 8:],
+        "blocks_off beyond the file": good[:hdr_blocks] + struct.pack("<Q", len(good) + 4096) + good[hdr_blocks + 8:],
+        "neighbour id out of range": good[:blocks_off + 7 * stride + 2048 + 512] + struct.pack("<I", n + 9)
+                                     + good[blocks_off + 7 * stride + 2048 + 512 + 4:],
+        "neighbour count 77": good[:blocks_off + 7 * stride + 2048 + 512 + 128] + struct.pack("<I", 77)
+                              + good[blocks_off + 7 * stride + 2048 + 512 + 128 + 4:],
+    }
+    for what, blob in cases.items():
+        pb = tmp_path / "bad.cphn"
+        pb.write_bytes(blob)
+        with pytest.raises(RuntimeError):
+            a.load_native(str(pb))
+        ids2, d2 = a.search_batch(Q, 10)
+        assert np.array_equal(ids2, ids) and _beq(d2, d), what
 
 
 def test_torch_can_initialise_after_the_library():
