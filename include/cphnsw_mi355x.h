@@ -93,6 +93,21 @@ int cph_knn_bruteforce(int device, const float* vectors, uint64_t n, uint64_t di
 int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* parent, const float* nbrs, uint64_t cnt,
                      uint8_t* values, float* aux, uint32_t* pops);
 
+/* Construction hook: the neighbour-selection kernel on ONE vertex with a given candidate list -- the rule of
+ * graph/neighbor_selection.hpp:21-88 (select_neighbors_alpha_cng), deterministic on a fixed list.  x = [n][D] padded
+ * vectors, fwd = 32 forward candidates (0xFFFFFFFF = none), rev = up to 96 further candidates (the reverse edges),
+ * err = per-vertex margin terms or null.  out_ids = 32 selected ids (0xFFFFFFFF padded), *out_cnt = how many. */
+int cph_select_hook(int device, const float* x, uint64_t n, uint64_t D, uint32_t vertex, const uint32_t* fwd,
+                    const uint32_t* rev, uint64_t n_rev, uint32_t R, float alpha, float tau, float alpha_max,
+                    const float* err, uint32_t* out_ids, uint32_t* out_cnt);
+
+/* Construction hook: the calibration sampler (api/hnsw_index.hpp:770-1040 gathers the same quantities) on given sample
+ * queries [ns][dim] and start vertices: per sample one greedy hop, then per edge of the vertex arrived at
+ * rec[ns][32][6] = {nop, ip_est_raw - ip_cp, max(|ip_qo|, 1e-10), <q - p, o - p> / nop, |q - o|^2, ip_qo};
+ * rec_cnt[ns] = valid edges, dqp[ns] = exact |q - p|^2. */
+int cph_calib_hook(cph_index* h, const float* queries, const uint32_t* start, uint64_t ns, float* rec, uint32_t* rec_cnt,
+                   float* dqp);
+
 /* Self-test hook for the beam's heap routines (wave-parallel std::push_heap / std::pop_heap with the first 255
  * entries in LDS and the rest in HBM, search/rabitq_search.hpp:53-58, :79-80): runs `ops` (1 = push the next
  * (key, id), 0 = pop) on one wave and returns the heap array; the test compares it with libstdc++'s on the same

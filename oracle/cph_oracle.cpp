@@ -933,6 +933,117 @@ int orc_exact_l2(void* h, const float* query, const uint32_t* ids, long n, float
     return 0;
 }
 
+// graph/neighbor_selection.hpp:21-88 (select_neighbors_alpha_cng) for one vertex: candidates = ids into x[n][D]
+// (kInvalid entries and the vertex itself are dropped, an id counts once); distances and the occlusion tests use
+// the 8-chain squared L2 of core/memory.hpp:65-79.  The reference sorts the deduplicated candidates with
+// std::sort on the distance alone, which leaves the order of equal distances unspecified; here ties are ordered
+// by id (the GPU kernel's order: a deterministic refinement).  err may be null (all margins zero).
+int orc_select_neighbors(int D, const float* x, uint32_t vtx, const uint32_t* cand, int n_cand, int R, float alpha,
+                         float tau, float alpha_max, const float* err, uint32_t* out, uint32_t* out_cnt) {
+    struct C { uint32_t id; float d; };
+    std::vector<C> c;
+    for (int i = 0; i < n_cand; ++i) {
+        if (cand[i] == kInvalid || cand[i] == vtx) continue;
+        bool seen = false;
+        for (const C& e : c) seen |= e.id == cand[i];
+        if (!seen) c.push_back({cand[i], l2sq8((size_t)D, x + (size_t)vtx * D, x + (size_t)cand[i] * D)});
+    }
+    std::sort(c.begin(), c.end(), [](const C& a, const C& b) { return a.d < b.d || (a.d == b.d && a.id < b.id); });
+    std::vector<uint32_t> sel;
+    if ((int)c.size() <= R) {
+        for (const C& e : c) sel.push_back(e.id);
+    } else {
+        if (alpha_max <= 0.0f) alpha_max = 2.0f * alpha;
+        float la = alpha * std::sqrt((float)c.size() / (float)R);
+        la = la < 1.0f ? 1.0f : (la > alpha_max ? alpha_max : la);
+        std::vector<char> taken(c.size(), 0);
+        for (size_t i = 0; i < c.size() && (int)sel.size() < R; ++i) {
+            const float errc = err ? err[c[i].id] : 0.0f;
+            bool add = true;
+            for (uint32_t e : sel) {
+                const float dce = l2sq8((size_t)D, x + (size_t)c[i].id * D, x + (size_t)e * D);
+                const float thr = la * c[i].d + (errc + (err ? err[e] : 0.0f)) - (la - 1.0f) * tau;
+                if (dce < thr) { add = false; break; }
+            }
+            if (add) { sel.push_back(c[i].id); taken[i] = 1; }
+        }
+        for (size_t i = 0; i < c.size() && (int)sel.size() < R; ++i)
+            if (!taken[i]) sel.push_back(c[i].id);
+    }
+    *out_cnt = (uint32_t)sel.size();
+    for (int i = 0; i < 32; ++i) out[i] = i < (int)sel.size() ? sel[i] : kInvalid;
+    return 0;
+}
+
+// One calibration sample as the builder evaluates it (api/hnsw_index.hpp:770-1040 gathers the same quantities on
+// the host): a greedy hop from `start` to its nearest neighbour if that is nearer to the query, then per edge of
+// the vertex arrived at: {nop, ip_est_raw - ip_cp, max(|ip_qo|, 1e-10), <q - p, o - p> / nop, |q - o|^2, ip_qo},
+// with the raw estimator  ip_est_raw = A/K * S_nbit + B/K * weighted_popcount + C  (K = 2^BW - 1; 1-bit: plain
+// sums and popcounts) of distance/fastscan_kernel.hpp:281.  rec = [32][6]; *dqp = exact |q - p|^2.
+int orc_calib_record(void* h, const float* query, uint32_t start, float* rec, uint32_t* cnt_out, float* dqp_out) {
+    Index* ix = static_cast<Index*>(h);
+    const size_t D = ix->D;
+    const Layout& L = ix->L;
+    std::vector<float> q(D, 0.0f);
+    std::memcpy(q.data(), query, ix->dim * sizeof(float));
+    QueryCode qc;
+    encode_query(*ix->rot, q.data(), qc, nullptr);
+    uint32_t parent = start;
+    float best = l2sq8(D, q.data(), ix->vec(parent));
+    {
+        const uint8_t* nb = ix->nb(parent);
+        const uint32_t* ids = (const uint32_t*)(nb + L.ids);
+        const uint32_t cnt = rd<uint32_t>(nb + L.count);
+        float cand = std::numeric_limits<float>::max();
+        uint32_t cand_id = kInvalid;
+        for (uint32_t i = 0; i < cnt && i < 32; ++i) {
+            const float dd = l2sq8(D, q.data(), ix->vec(ids[i]));
+            if (dd < cand) { cand = dd; cand_id = ids[i]; }
+        }
+        if (cand_id != kInvalid && cand < best) { best = cand; parent = cand_id; }
+    }
+    const uint8_t* nb = ix->nb(parent);
+    const float* nop = (const float*)(nb + L.nop);
+    const float* ipqo = (const float*)(nb + L.ip_qo);
+    const float* ipcp = (const float*)(nb + L.ip_cp);
+    const uint16_t* pop = (const uint16_t*)(nb + L.pop);
+    const uint32_t* ids = (const uint32_t*)(nb + L.ids);
+    const uint32_t cnt = std::min<uint32_t>(32, rd<uint32_t>(nb + L.count));
+    uint32_t sums[32], msb[32];
+    if (ix->bw == 1) plane_sums(D, qc.lut.data(), nb + L.codes, sums);
+    else nbit_sums(D, ix->bw, qc.lut.data(), nb + L.codes, sums, msb);
+    const float* p = ix->vec(parent);
+    for (uint32_t i = 0; i < 32; ++i) {
+        float ipa;
+        if (ix->bw == 1) {
+            ipa = qc.A * (float)sums[i] + qc.B * (float)pop[i] + qc.C;
+        } else {
+            const uint16_t* wpop = (const uint16_t*)(nb + L.wpop);
+            const float invK = 1.0f / (float)((1u << ix->bw) - 1);
+            ipa = qc.A * invK * (float)sums[i] + qc.B * invK * (float)wpop[i] + qc.C;
+        }
+        const float ipq = std::fabs(ipqo[i]) > 1e-10f ? std::fabs(ipqo[i]) : 1e-10f;
+        const float nopf = nop[i] > 1e-12f ? nop[i] : 1e-12f;
+        float tip = 0.0f, dqo = 0.0f;
+        if (i < cnt) {
+            const float* o = ix->vec(ids[i]);
+            float t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t d = 0; d < D; d += 8)
+                for (int j = 0; j < 8; ++j) {
+                    t[j] = std::fmaf(q[d + j] - p[d + j], o[d + j] - p[d + j], t[j]);
+                    l[j] = std::fmaf(q[d + j] - o[d + j], q[d + j] - o[d + j], l[j]);
+                }
+            tip = reduce8(t);
+            dqo = reduce8(l);
+        }
+        float* r = rec + i * 6;
+        r[0] = nopf; r[1] = ipa - ipcp[i]; r[2] = ipq; r[3] = i < cnt ? tip / nopf : 0.0f; r[4] = dqo; r[5] = ipqo[i];
+    }
+    *cnt_out = cnt;
+    *dqp_out = best;
+    return 0;
+}
+
 // Streaming FastScan over contiguous reference-layout neighbour blocks (scalar port;
 // the cpu_baseline "port" leg of bench.py when oracle/_ref is absent).
 int orc_fastscan_stream(int D, int bits, const uint8_t* lut, const float* qp7, const uint8_t* blocks,

@@ -2,6 +2,7 @@
 
     from cphnsw_mi355x import CPIndex      # drop-in for `from cphnsw import CPIndex`
 """
-from .index import CPIndex, FastScanStream, encode_edges, heap_ops_debug, knn_bruteforce  # noqa: F401
+from .index import (CPIndex, FastScanStream, encode_edges, heap_ops_debug, knn_bruteforce,  # noqa: F401
+                    select_neighbors_debug)
 
-__all__ = ["CPIndex", "FastScanStream", "encode_edges", "heap_ops_debug", "knn_bruteforce"]
+__all__ = ["CPIndex", "FastScanStream", "encode_edges", "heap_ops_debug", "knn_bruteforce", "select_neighbors_debug"]

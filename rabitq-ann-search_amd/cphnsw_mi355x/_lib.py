@@ -27,6 +27,9 @@ SYMBOLS = {
                                      C.c_void_p, C.c_void_p]),
     "cph_debug_heap_ops": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
+    "cph_select_hook": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                  C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cph_calib_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cph_encode_edges": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "cph_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -121,6 +121,18 @@ class CPIndex:
     def load(self, path):
         _lib.check(_lib.lib().cph_load(self._h, str(path).encode()))
 
+    def calib_samples_debug(self, queries, start):
+        """Construction hook: the calibration sampler on given queries / start vertices: (rec [ns, 32, 6], cnt, dqp)."""
+        q = _as_f32(queries)
+        st = np.ascontiguousarray(start, np.uint32)
+        ns = q.shape[0]
+        rec = np.zeros((ns, 32, 6), np.float32)
+        cnt = np.zeros(ns, np.uint32)
+        dqp = np.zeros(ns, np.float32)
+        _lib.check(_lib.lib().cph_calib_hook(self._h, q.ctypes.data, st.ctypes.data, ns, rec.ctypes.data, cnt.ctypes.data,
+                                             dqp.ctypes.data))
+        return rec, cnt, dqp
+
     def save_native(self, path):
         """GPU-native file (device block layout; not readable by the reference): fast to load."""
         _lib.check(_lib.lib().cph_save_native(self._h, str(path).encode()))
@@ -269,6 +281,24 @@ def encode_edges(parent, nbrs, bits, device=None):
     _lib.check(_lib.lib().cph_encode_edges(dev, dim, int(bits), p.ctypes.data, nb.ctypes.data, cnt, vals.ctypes.data,
                                            aux.ctypes.data, pops.ctypes.data))
     return vals, aux, pops
+
+
+def select_neighbors_debug(x, vertex, fwd, rev, R, alpha, tau, alpha_max=0.0, err=None, device=None):
+    """Construction hook: the GPU selection kernel on one vertex (x = [n, D] padded vectors, fwd = 32 candidate ids with
+    0xFFFFFFFF for none, rev = up to 96 more).  Returns the selected ids."""
+    x = _as_f32(x)
+    n, D = x.shape
+    fwd = np.ascontiguousarray(fwd, np.uint32)
+    rev = np.ascontiguousarray(rev, np.uint32)
+    assert fwd.shape == (32,)
+    out = np.zeros(32, np.uint32)
+    cnt = np.zeros(1, np.uint32)
+    e = None if err is None else _as_f32(err)
+    dev = _default_device() if device is None else int(device)
+    _lib.check(_lib.lib().cph_select_hook(dev, x.ctypes.data, n, D, int(vertex), fwd.ctypes.data, rev.ctypes.data if len(rev) else None,
+                                          len(rev), int(R), float(alpha), float(tau), float(alpha_max),
+                                          None if e is None else e.ctypes.data, out.ctypes.data, cnt.ctypes.data))
+    return out[:cnt[0]].copy()
 
 
 def heap_ops_debug(ops, keys, ids, device=None):

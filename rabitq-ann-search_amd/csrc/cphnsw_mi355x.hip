@@ -838,6 +838,81 @@ int cph_encode_edges(int device, uint64_t dim, uint64_t bits, const float* paren
     });
 }
 
+int cph_select_hook(int device, const float* x, uint64_t n, uint64_t D, uint32_t vertex, const uint32_t* fwd,
+                    const uint32_t* rev, uint64_t n_rev, uint32_t R, float alpha, float tau, float alpha_max,
+                    const float* err, uint32_t* out_ids, uint32_t* out_cnt) {
+    return guarded([&] {
+        if (!x || !fwd || !out_ids || !out_cnt || n == 0 || vertex >= n) throw InvalidArg("bad arguments");
+        if (D < 16 || D > 2048 || (D & (D - 1))) throw InvalidArg("D must be a power of two in 16..2048");
+        if (R == 0 || R > 32 || n_rev > 96) throw InvalidArg("R must be 1..32 and n_rev <= 96 (the hub path is not a unit case)");
+        for (int i = 0; i < 32; ++i)
+            if (fwd[i] != kInvalidNode && fwd[i] >= n) throw InvalidArg("candidate out of range");
+        for (uint64_t i = 0; i < n_rev; ++i)
+            if (rev[i] >= n) throw InvalidArg("candidate out of range");
+        HIP_CHECK(hipSetDevice(device));
+        // one row: the vertex is row 0 of a one-row layer (row_ids = {vertex}), reverse candidates are row indices of
+        // a table that maps them back to the given vertex ids
+        DevBuf<float> d_x(n * D), d_err(n);
+        DevBuf<uint32_t> d_fwd(32), d_rev(std::max<uint64_t>(1, n_rev)), d_rows(std::max<uint64_t>(1, n_rev) + 1), d_out(32), d_cnt(1);
+        DevBuf<uint64_t> d_off(2);
+        HIP_CHECK(hipMemcpy(d_x.p, x, n * D * 4, hipMemcpyHostToDevice));
+        if (err) HIP_CHECK(hipMemcpy(d_err.p, err, n * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_fwd.p, fwd, 128, hipMemcpyHostToDevice));
+        // row 0 = the vertex itself; reverse candidate i is "row i + 1", whose vertex id is rev[i]
+        std::vector<uint32_t> rows(n_rev + 1), revrows(std::max<uint64_t>(1, n_rev));
+        rows[0] = vertex;
+        for (uint64_t i = 0; i < n_rev; ++i) { rows[i + 1] = rev[i]; revrows[i] = (uint32_t)(i + 1); }
+        HIP_CHECK(hipMemcpy(d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_rev.p, revrows.data(), revrows.size() * 4, hipMemcpyHostToDevice));
+        const uint64_t off[2] = {0, n_rev};
+        HIP_CHECK(hipMemcpy(d_off.p, off, 16, hipMemcpyHostToDevice));
+        build::SelectArgs a{};
+        a.x = d_x.p; a.fwd = d_fwd.p; a.rev_off = d_off.p; a.rev = d_rev.p; a.row_ids = d_rows.p; a.err = err ? d_err.p : nullptr;
+        a.rows = 1; a.D = (uint32_t)D; a.R = R; a.alpha = alpha; a.tau = tau; a.alpha_max = alpha_max;
+        a.out = d_out.p; a.out_cnt = d_cnt.p;
+        hipLaunchKernelGGL(build::select_kernel, dim3(1), dim3(64), build::select_lds(a.D), nullptr, a);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out_ids, d_out.p, 128, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(out_cnt, d_cnt.p, 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int cph_calib_hook(cph_index* h, const float* queries, const uint32_t* start, uint64_t ns, float* rec, uint32_t* rec_cnt,
+                   float* dqp) {
+    return guarded([&] {
+        if (!h || !queries || !start || !rec || !rec_cnt || !dqp || ns == 0 || ns > 0xFFFFFFull) throw InvalidArg("bad arguments");
+        std::lock_guard<std::mutex> lk(h->mu);
+        require_finalized(h);
+        for (uint64_t i = 0; i < ns; ++i)
+            if (start[i] >= h->host.n) throw InvalidArg("start vertex out of range");
+        h->use_device();
+        hipStream_t st = own_stream(h);
+        BatchSet& s = next_set(h, st);
+        stage_queries(h, s, upload_queries(h, s, queries, ns, st), ns, st);     // the search's own encoder
+        HIP_CHECK(hipEventRecord(s.ev_done, st));
+        s.used = true;
+        DevBuf<uint32_t> d_start(ns), d_rc(ns);
+        DevBuf<float> d_rec(ns * 32 * 6), d_dqp(ns);
+        HIP_CHECK(hipMemcpyAsync(d_start.p, start, ns * 4, hipMemcpyHostToDevice, st));
+        build::CalibArgs c{};
+        c.blocks = h->d_blocks.p; c.raw = h->d_raw.p; c.L = h->L; c.n = h->host.n;
+        c.queries = s.d_queries.p; c.qmasks = s.d_qmasks.p; c.qhdr = s.d_qhdr.p;
+        c.start = d_start.p; c.ns = (uint32_t)ns; c.rec = d_rec.p; c.rec_cnt = d_rc.p; c.dqp_out = d_dqp.p;
+        const size_t lds = (size_t)h->L.PW * 16 + (size_t)h->L.D * 8;
+        const dim3 grid((uint32_t)std::min<uint64_t>(ns, (uint64_t)h->num_cus * 16));
+        if (h->bits == 1) hipLaunchKernelGGL(build::calib_kernel<1>, grid, dim3(64), lds, st, c);
+        else if (h->bits == 2) hipLaunchKernelGGL(build::calib_kernel<2>, grid, dim3(64), lds, st, c);
+        else hipLaunchKernelGGL(build::calib_kernel<4>, grid, dim3(64), lds, st, c);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(s.ev_done, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpy(rec, d_rec.p, ns * 32 * 6 * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(rec_cnt, d_rc.p, ns * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dqp, d_dqp.p, ns * 4, hipMemcpyDeviceToHost));
+    });
+}
+
 int cph_get_vectors(cph_index* h, uint64_t first, uint64_t count, float* out) {
     return guarded([&] {
         if (!h || !out) throw InvalidArg("null argument");

@@ -413,61 +413,88 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
     };
     // levels 8..12: the page of the level-7 node (read whenever that node has a child at all, so that every path
     // entry of these levels -- including a last left-only child -- is in some lane's registers)
+    const uint32_t pbase = (hp - 128u) * kPageDwords;     // wave-uniform: everything below addresses the page relative to it
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
     uint32_t steps = 0;
     if (2 * hp - 1 < len) {
         const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
-        if (lane < 62 && idx < len) w = h.gload((hp - 128u) * kPageDwords + 3u * r);
+        if (lane < 62 && idx < len) w = h.gload(pbase + 3u * r);
         steps = walk(__uint_as_float(w.x), idx);
     }
     // levels 13+: windows of keys over the heap-ordered tail
     while (steps == 5 && 2 * hp < len) {
         const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
         float key = 0.0f;
-        if (lane < 62 && idx < len) key = __uint_as_float(h.g[beam_spill_off(idx)]);
+        if (lane < 62 && idx < len) key = __uint_as_float(h.g[kBeamTail + 3u * (idx - kBeamPaged)]);
         steps = walk(key, idx);
     }
     if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
         hp = 2 * hp;
         ++d;
     }
-    // the moves (heap_pop_wave's second half; d <= 31 lanes take part).  Lane t moves the entry at p_(t+1) to p_t.
-    const uint32_t hole = hp - 1;
+    // the moves (heap_pop_wave's second half; d <= 31 lanes take part).  Lane t moves the entry at p_(t+1) to p_t;
+    // p_t sits on heap level t: LDS up to level 7, the page (relative node = the level's bits of the path string
+    // under a leading one) up to level 12, the tail beyond.
     const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
-    const uint32_t my_dst = (hp >> (d - t)) - 1;
+    const uint32_t dst_hp = hp >> (d - t);                                     // p_t + 1
     const uint32_t src_hp = hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u));    // p_(t+1) + 1, level t + 1
-    const uint32_t my_src = src_hp - 1;
+    auto page_rel = [](uint32_t node_hp, uint32_t lvl) {                        // lvl = heap level - 7, 1..5
+        return (node_hp & ((1u << lvl) - 1u)) | (1u << lvl);
+    };
+    auto put_level = [&](uint32_t level, uint32_t node_hp, uint4 val) {
+        if (level <= 7) h.lds_put(node_hp - 1, val);
+        else if (level <= 12) h.gstore(pbase + 3u * page_rel(node_hp, level - 7u), val);
+        else h.gstore(kBeamTail + 3u * (node_hp - (kBeamPaged + 1)), val);
+    };
     // sources on levels 8..12 come out of the window lane that read them: relative node -> lane r - 2
     const bool from_page = (uint32_t)lane < d && t >= 7 && t <= 11;
-    const uint32_t lvl = from_page ? t - 6u : 1u;
-    const int page_lane = (int)(((src_hp & ((1u << lvl) - 1u)) | (1u << lvl)) - 2u);
+    const int page_lane = (int)page_rel(src_hp, from_page ? t - 6u : 1u) - 2;
     const uint4 pw = make_uint4((uint32_t)__shfl((int)w.x, page_lane), (uint32_t)__shfl((int)w.y, page_lane),
                                 (uint32_t)__shfl((int)w.z, page_lane), 0u);
     uint4 e = v;
     bool c = false;
     if ((uint32_t)lane < d) {
-        if (t < 7) e = h.lds(my_src);
+        if (t < 7) e = h.lds(src_hp - 1);
         else if (t <= 11) e = pw;
-        else e = h.gload(beam_spill_off(my_src));
+        else e = h.gload(kBeamTail + 3u * (src_hp - (kBeamPaged + 1)));
         c = Beam::before(Beam::key_of(e), Beam::key_of(v));
     }
     const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
     const uint32_t fin = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;
-    if ((uint32_t)lane < fin) h.put(my_dst, e);
-    if (fin == d) { if (lane == 0) h.put(hole, v); }
-    else if ((uint32_t)lane == fin) h.put(my_dst, v);
+    if ((uint32_t)lane < fin) put_level(t, dst_hp, e);
+    if (fin == d) { if (lane == 0) put_level(d, hp, v); }
+    else if ((uint32_t)lane == fin) put_level(t, dst_hp, v);
 }
 
 // std::push_heap of `v` at index `hole` >= kBeamLds: heap_push_wave on the hybrid accessors -- the ancestors of the
-// leaf (LDS or HBM, by index) are read by one lane each, one round trip whatever the depth.
+// leaf (LDS or HBM, by index) are read by one lane each, one round trip whatever the depth.  A leaf inside the pages
+// (hole < 8191: the usual case) has all its HBM ancestors in its own page, at the leaf's relative index shifted right.
 __device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, uint4 v, int lane) {
     const uint32_t hp = hole + 1;
     const uint32_t depth = 31u - (uint32_t)__builtin_clz(hp);
     const uint32_t t = (uint32_t)lane + 1;
     const bool on = t <= depth;
-    const uint32_t pt = on ? (hp >> t) - 1 : 0u;
     uint4 e = v;
     bool down = false;
+    if (hp <= kBeamPaged) {
+        const uint32_t lvl = depth - 7u;                                       // 1..5 (wave-uniform, like everything up to rl)
+        const uint32_t pbase = ((hp >> lvl) - 128u) * kPageDwords;
+        const uint32_t rl = (hp & ((1u << lvl) - 1u)) | (1u << lvl);           // the leaf's relative index in its page
+        // ancestor p_t sits on level depth - t: in the page while t < lvl (relative index rl >> t), in LDS above
+        if (on) {
+            if (t < lvl) e = h.gload(pbase + 3u * (rl >> t)); else e = h.lds((hp >> t) - 1);
+            down = Beam::before(Beam::key_of(e), Beam::key_of(v));
+        }
+        const unsigned long long stop = ~__ballot(down);
+        const uint32_t m = (uint32_t)__builtin_ctzll(stop);
+        auto put_anc = [&](uint32_t s, uint4 val) {                            // ancestor p_s (s = 0: the leaf)
+            if (s < lvl) h.gstore(pbase + 3u * (rl >> s), val); else h.lds_put((hp >> s) - 1, val);
+        };
+        if (t <= m) put_anc(t - 1, e);
+        if ((uint32_t)lane == m) put_anc(m, v);
+        return;
+    }
+    const uint32_t pt = on ? (hp >> t) - 1 : 0u;
     if (on) {
         e = h.raw(pt);
         down = Beam::before(Beam::key_of(e), Beam::key_of(v));
@@ -758,16 +785,23 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // expansion's time when it ran in front of the loads) now hide behind the block's memory latency.
             // LDS and scalar work only (lgkmcnt), so no wait on the loads (vmcnt) is forced here.
             // Spilled beams: the pushes at the end of this expansion will compare against the ancestors of the leaf the
-            // pop is about to free (heap index beam_size - 1).  Those of them that live in HBM are touched now, one per
-            // lane, in the same round trip as the block: the pushes' own reads then hit in L2 instead of being another
-            // dependent trip to HBM.  (Always issued -- a load that is only sometimes in flight would turn the compiler's
-            // later counted waits into vmcnt(0) -- lanes with nothing to touch read the slot's first word; the value is
-            // consumed, unused, where the block's loads are retired anyway.)
-            uint32_t touch;
-            {
-                const uint32_t tp = (beam_size >> ((uint32_t)lane + 1u)) - 1u;       // ancestor t = lane + 1 of heap index beam_size - 1
-                const bool on = beam_size > kBeamLds && lane < 31 && (beam_size >> ((uint32_t)lane + 1u)) > kBeamLds;
-                touch = heap.g[on ? beam_spill_off(tp) : 0u];
+            // pop is about to free (heap index beam_size - 1).  Those of them that live in the pages are touched now, one
+            // per lane, in the same round trip as the block: the pushes' own reads then hit in L2 instead of being another
+            // dependent trip to HBM.  The value is consumed, unused, where the block's loads are retired anyway (the touch
+            // is the youngest load there, so the compiler's wait for it is the wait the block needs in any case); beams
+            // that fit the LDS levels -- every C2 expansion -- skip the whole thing on a wave-uniform branch.
+            uint32_t touch = 0;
+            if (beam_size > kBeamLds) {
+                // leaf = heap index beam_size - 1, i.e. hp = beam_size on level `depth`; its ancestor on level 7 + j
+                // (j = 1..5, below the leaf's own level) is relative node ((hp >> (depth - 7 - j)) & (2^j - 1)) | 2^j
+                // of the page of hp >> (depth - 7): lane j - 1 touches it
+                const uint32_t depth = 31u - (uint32_t)__builtin_clz(beam_size);
+                const uint32_t j = (uint32_t)lane + 1u;
+                const bool on = j <= 5u && 7u + j < depth;
+                const uint32_t sh = on ? depth - 7u - j : 0u;
+                const uint32_t rj = ((beam_size >> sh) & ((1u << (j & 7u)) - 1u)) | (1u << (j & 7u));
+                const uint32_t pb = ((beam_size >> (depth - 7u)) - 128u) * kPageDwords;
+                touch = heap.g[on ? pb + 3u * rj : 0u];
             }
             pop_beam(beam_size);
             --beam_size;

@@ -120,17 +120,47 @@ def pop_hybrid(h, size):
             cs[lane] = before(e[0], v[0])
     stay = [lane for lane in range(d) if not cs[lane]]
     fin = (max(stay) + 1) if stay else 0
+    pbase = ((hp >> (d - 7)) - 128) * PD
+
+    def page_rel(node_hp, lvl):
+        return (node_hp & ((1 << lvl) - 1)) | (1 << lvl)
+
+    def put_level(level, node_hp, val):      # the kernel's specialised addressing must agree with the placement function
+        if level <= 7:
+            assert node_hp - 1 < KL
+        elif level <= 12:
+            assert pbase + 3 * page_rel(node_hp, level - 7) == off(node_hp - 1), (level, node_hp)
+        else:
+            assert TAIL + 3 * (node_hp - (PAGED + 1)) == off(node_hp - 1)
+        h.put(node_hp - 1, val)
+
     for lane in range(fin):
-        h.put(dsts[lane], es[lane])
+        put_level(lane, hp >> (d - lane), es[lane])
     if fin == d:
-        h.put(hole, v)
+        put_level(d, hp, v)
     else:
-        h.put(dsts[fin], v)
+        put_level(fin, hp >> (d - fin), v)
 
 
 def push_hybrid(h, hole, v):
     hp = hole + 1
     depth = 31 - clz32(hp)
+    if KL <= hole and hp <= PAGED:           # the kernel's fast path: every HBM ancestor in the leaf's own page
+        lvl = depth - 7
+        pbase = ((hp >> lvl) - 128) * PD
+        rl = (hp & ((1 << lvl) - 1)) | (1 << lvl)
+        for s in range(0, depth + 1):
+            if s < lvl:
+                assert pbase + 3 * (rl >> s) == off((hp >> s) - 1), (hole, s)
+            else:
+                assert (hp >> s) - 1 < KL
+    if hole >= KL:                           # the touch of the expansion head: ancestors of levels 8..12 below the leaf's level
+        pb = ((hp >> (depth - 7)) - 128) * PD
+        for j in range(1, 6):
+            if 7 + j < depth:
+                sh = depth - 7 - j
+                rj = ((hp >> sh) & ((1 << j) - 1)) | (1 << j)
+                assert pb + 3 * rj == off((hp >> sh) - 1), (hole, j)
     es, down = {}, {}
     for t in range(1, depth + 1):
         pt = (hp >> t) - 1

@@ -141,6 +141,19 @@ class _Hooks:
         assert f(ops, len(ops), keys, ids, ok, oi, sz) == 0
         return ok[:sz[0]].copy(), oi[:sz[0]].copy()
 
+    def select_neighbors(self, x, vertex, cand, R, alpha, tau, alpha_max=0.0, err=None):
+        """graph/neighbor_selection.hpp:21-88 on a candidate list (ties by id); x = [n, D] padded vectors."""
+        x = _c(x, np.float32)
+        cand = _c(cand, np.uint32)
+        out = np.zeros(32, np.uint32)
+        cnt = np.zeros(1, np.uint32)
+        f = self._f("select_neighbors")
+        f.argtypes = [C.c_int, f32p, C.c_uint32, u32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, u32p, u32p]
+        e = None if err is None else _c(err, np.float32)
+        assert f(x.shape[1], x, int(vertex), cand, len(cand), int(R), float(alpha), float(tau), float(alpha_max),
+                 None if e is None else e.ctypes.data, out, cnt) == 0
+        return out[:cnt[0]].copy()
+
     def dot(self, a, b):
         out = np.zeros(1, np.float32)
         f = self._f("dot")
@@ -208,6 +221,16 @@ class OracleIndex:
         if rc != 0:
             raise RuntimeError("Search failed: invalid entry point after finalize.")
         return (ids, d, cnt, ctr) if counters else (ids, d, cnt)
+
+    def calib_record(self, query, start):
+        """One calibration sample (oracle/cph_oracle.cpp: orc_calib_record): (rec [32, 6], valid edges, dqp)."""
+        rec = np.zeros((32, 6), np.float32)
+        cnt = C.c_uint32()
+        dqp = C.c_float()
+        f = self.o.lib.orc_calib_record
+        f.argtypes = [C.c_void_p, f32p, C.c_uint32, f32p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        assert f(self.h, _c(query, np.float32), int(start), rec, C.byref(cnt), C.byref(dqp)) == 0
+        return rec, cnt.value, np.float32(dqp.value)
 
     def entry_point(self, query):
         ep = C.c_uint32()

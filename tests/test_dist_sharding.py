@@ -106,6 +106,77 @@ def test_packed_gather_is_one_collective_and_rank_major(gold):
         assert d.tobytes() == gold["S/g128/b4/plain/k10/d"][:world * nq].tobytes()
 
 
+def _bench_step_worker(rank, world, port, nq, k, q):
+    """bench.py's own N > 1 control flow (make_step + timed_region: priming, warm-up, barrier, K steps alternating two
+    scratch sets, the packed all-gather inside the step, MAX of the elapsed time over ranks) on CPU tensors over gloo.
+    The search itself is stood in for by the oracle on the rank's query shard (test infrastructure)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    from golden_util import fixture_path, golden
+    from oracle_lib import Oracle
+    from cphnsw_mi355x.dist import PackedResults
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oi = Oracle().load(fixture_path("g128", 4))
+        Q = golden()["Q/g128"]
+        q_shard = torch.from_numpy(Q[rank * nq:(rank + 1) * nq])
+        calls = []
+
+        def search_device(qs, kk, out, stream):
+            ids, d, _ = oi.search_batch(qs.numpy(), kk, nthreads=1)
+            out[0].copy_(torch.from_numpy(ids))
+            out[1].copy_(torch.from_numpy(d))
+            calls.append(stream)
+            if rank == 1:
+                time.sleep(0.01)          # an uneven rank: the reported time must be the slowest rank's
+            return out
+
+        dev = torch.device("cpu")
+        packs = [PackedResults(nq, k, world, dev) for _ in range(2)]
+        step = bench.make_step(search_device, q_shard, k, packs, ["s0", "s1"], True, lambda st: bench.NullStream())
+        steps, warmup = 4, 1
+        t0 = time.perf_counter()
+        el, ids, d = bench.timed_region(step, steps, warmup, False, True, dist, lambda: None, dev)
+        wall = time.perf_counter() - t0
+        assert len(calls) == 2 + warmup + steps and calls[-2:] == ["s0", "s1"]       # steps alternate the two sets
+        # after the last step (i = 3 -> set 1) that set's gather buffer holds the whole batch, rank-major
+        nqk = nq * k
+        all_ids = packs[1].all[:, : nqk * 8].contiguous().view(torch.int64).view(world * nq, k)
+        all_d = packs[1].all[:, nqk * 8:].contiguous().view(torch.float32).view(world * nq, k)
+        q.put((rank, el, wall, all_ids.numpy().copy(), all_d.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_and_timed_region_over_gloo(gold):
+    """The N > 1 path of bench.py executed end to end on two ranks before the driver's first multi-GPU run."""
+    world, k, nq = 2, 10, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_step_worker, args=(r, world, port, nq, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    els = {r[0]: r[1] for r in res}
+    assert els[0] == els[1]                                  # the all-reduced MAX: every rank reports the same time
+    assert els[0] >= 4 * 0.01                                # ... the slow rank's (4 timed steps x 10 ms of extra work)
+    for _, el, wall, ids, d in res:
+        assert el <= wall
+        assert np.array_equal(ids, gold["S/g128/b4/plain/k10/ids"][:world * nq])
+        assert d.tobytes() == gold["S/g128/b4/plain/k10/d"][:world * nq].tobytes()
+
+
 def test_shard_bounds_cover_everything():
     from cphnsw_mi355x.dist import shard_bounds
     for n in (0, 1, 7, 8, 10_000, 10_001):

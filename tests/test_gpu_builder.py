@@ -11,6 +11,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def cph():
+    import cphnsw_mi355x
+    return cphnsw_mi355x
+
+
 def sift_like(rng, n, dim, ncl):
     cent = rng.gamma(2, 15, (ncl, dim))
     X = cent[rng.integers(0, ncl, n)] + rng.normal(0, 12, (n, dim))
@@ -171,6 +177,46 @@ def test_graph_quality_not_worse_than_reference(tmp_path):
     assert rec_m >= rec_r - 0.05
 
 
+def test_graph_quality_at_benchmark_scale_tracks_the_reference(tmp_path):
+    """The gate that would catch a graph-quality regression at a size that is benchmarked: clustered, integer-valued
+    100k x 128 at 4 bits (BASELINE.md 2.2's generator: 1,000 clusters), built by this repo's GPU builder and by the
+    compiled reference (it can finalize up to ~230k vertices, finding F9); same search protocol on both; dedup
+    recall@10 of k = 20 and of k = 100 must be within 0.03 of the reference's."""
+    import cphnsw_mi355x
+    from oracle_lib import ref_available, ref_module
+    if not ref_available():
+        pytest.skip("oracle/_ref not present")
+    rng = np.random.default_rng(11)
+    n, dim, bits, nq = 100_000, 128, 4, 300
+    X, cent = sift_like(rng, n, dim, 1000)
+    Q = np.clip(np.round(cent[rng.integers(0, 1000, nq)] + rng.normal(0, 12, (nq, dim))), 0, 218).astype(np.float32)
+    gt = brute_topk(X, Q, 10)
+    mine = cphnsw_mi355x.CPIndex(dim, bits)
+    mine.build(X)
+    mine.finalize()
+    pm = str(tmp_path / "mine.idx")
+    mine.save(pm)
+    ref = ref_module().CPIndex(dim, bits)
+    ref.build(X)
+    ref.finalize()
+    pr = str(tmp_path / "ref.idx")
+    ref.save(pr)
+    key = {X[i].tobytes(): i for i in range(n)}
+
+    def rows_of(path):
+        raw = index_rows(path, n, dim, 128)
+        return [key[raw[i].tobytes()] for i in range(n)]
+
+    rm, rr = rows_of(pm), rows_of(pr)
+    for k in (20, 100):
+        ids_m, _ = mine.search_batch(Q, k)
+        ids_r, _ = ref.search_batch(Q, k)
+        rec_m = dedup_recall(ids_m, rm, gt, X)
+        rec_r = dedup_recall(ids_r, rr, gt, X)
+        print(f"100k clustered, 4-bit: dedup recall@10 of k={k}: ours {rec_m:.4f}, reference {rec_r:.4f}")
+        assert rec_m >= rec_r - 0.03, (k, rec_m, rec_r)
+
+
 def test_build_errors():
     import cphnsw_mi355x
     ix = cphnsw_mi355x.CPIndex(128, 4)
@@ -183,3 +229,51 @@ def test_build_errors():
     ix.build(np.random.default_rng(0).standard_normal((30, 128)).astype(np.float32))
     with pytest.raises(RuntimeError, match="at least 50 nodes"):
         ix.finalize()
+
+
+@pytest.mark.parametrize("D,n_rev,R,seed", [(128, 0, 32, 1), (128, 40, 32, 2), (128, 96, 32, 3), (16, 96, 18, 4), (1024, 60, 32, 5),
+                                            (64, 96, 24, 6), (128, 10, 8, 7)])
+def test_select_kernel_matches_the_rule_on_fixed_candidates(cph, oracle, D, n_rev, R, seed):
+    """select_kernel (device_build.h) on one vertex with a given candidate list against the oracle's restatement of
+    select_neighbors_alpha_cng (graph/neighbor_selection.hpp:21-88): the selected id LIST must be identical -- order
+    included -- for clustered data (occlusions happen), repeated candidates, the vertex itself among the candidates,
+    empty forward slots, error margins, equal distances (integer-valued rows) and lists shorter than R."""
+    rng = np.random.default_rng(seed)
+    n = 400
+    cent = rng.normal(0, 4, (6, D))
+    x = (cent[rng.integers(0, 6, n)] + rng.normal(0, 1, (n, D))).astype(np.float32)
+    if seed % 2 == 0:
+        x = np.round(x)                                  # ties in the distances
+    for trial in range(6):
+        v = int(rng.integers(0, n))
+        fwd = rng.choice(n, 32, replace=False).astype(np.uint32)
+        fwd[rng.integers(0, 32, 3)] = 0xFFFFFFFF          # empty slots
+        fwd[5] = v                                        # the vertex itself
+        rev = rng.choice(n, n_rev, replace=False).astype(np.uint32) if n_rev else np.zeros(0, np.uint32)
+        if n_rev >= 4:
+            rev[:2] = fwd[fwd != 0xFFFFFFFF][:2]          # ids that appear twice
+        err = None if trial % 2 == 0 else np.abs(rng.normal(0, 0.3, n)).astype(np.float32)
+        alpha, tau, amax = (1.2, 0.5, 0.0) if trial < 3 else (1.05, 2.0, 1.6)
+        got = cph.select_neighbors_debug(x, v, fwd, rev, R, alpha, tau, amax, err)
+        want = oracle.select_neighbors(x, v, np.concatenate([fwd, rev]), R, alpha, tau, amax, err)
+        assert np.array_equal(got, want), (D, n_rev, R, trial, got, want)
+        assert len(got) <= R and v not in got and len(set(got.tolist())) == len(got)
+
+
+@pytest.mark.parametrize("name,bits", [("g128", 4), ("g128", 2), ("g128", 1), ("sift96", 4), ("g16", 2), ("g1024", 2)])
+def test_calib_kernel_records_match_the_oracle(cph, gold, name, bits):
+    """calib_kernel's per-sample record on reference-built fixtures -- greedy hop, raw FastScan estimator term,
+    floored ip_qo, exact <q - p, o - p> / nop and |q - o|^2 per edge -- against the oracle's block functions, bit for bit."""
+    from golden_util import DATASETS, fixture_path
+    from oracle_lib import Oracle
+    ix = cph.CPIndex(DATASETS[name]["dim"], bits)
+    ix.load(fixture_path(name, bits))
+    oi = Oracle().load(fixture_path(name, bits))
+    Q = gold[f"Q/{name}"]
+    rng = np.random.default_rng(7)
+    start = rng.integers(0, DATASETS[name]["n"], len(Q)).astype(np.uint32)
+    rec, cnt, dqp = ix.calib_samples_debug(Q, start)
+    for i in range(len(Q)):
+        orec, ocnt, odqp = oi.calib_record(Q[i], start[i])
+        assert cnt[i] == ocnt and dqp[i].tobytes() == odqp.tobytes(), (i, cnt[i], ocnt, dqp[i], odqp)
+        assert rec[i, :ocnt].tobytes() == orec[:ocnt].tobytes(), (i, np.argwhere(rec[i, :ocnt] != orec[:ocnt])[:4])
