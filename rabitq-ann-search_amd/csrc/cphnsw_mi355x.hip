@@ -95,14 +95,19 @@ struct BatchSet {
     // [17] lo = work-queue counter of the re-run launch
     DevBuf<unsigned long long> d_stats;
     unsigned long long* pin_stats = nullptr;   // pinned host copy, written at the end of every batch
+    // small batches (cph_search, cph_search_batch with a handful of queries): queries are read and results written by
+    // the kernels straight from / to this pinned, device-mapped host buffer -- no copy commands at all
+    uint8_t* pin_io = nullptr;
+    uint8_t* pin_io_dev = nullptr;
+    size_t pin_io_bytes = 0;
     // per-slot scratch (estimated-set bitmap, beam spill area, id log), `cap` entries per slot
     DevBuf<uint32_t> d_bitmaps, d_logids;
-    DevBuf<uint32_t> d_beam;
+    DevBuf<uint32_t> d_beam, d_beam_tail;
     uint32_t slots = 0;
     uint64_t cap = 0;
     // full-capacity (n + 1) scratch of the overflow re-run launch
     DevBuf<uint32_t> r_bitmaps, r_logids;
-    DevBuf<uint32_t> r_beam;
+    DevBuf<uint32_t> r_beam, r_beam_tail;
     uint32_t r_slots = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     bool used = false;        // a batch has been enqueued on this set (ev_done is meaningful)
@@ -110,6 +115,7 @@ struct BatchSet {
     uint32_t run_slots = 0;   // slots its search launch used
 };
 constexpr int kStatWords = 18;
+constexpr uint64_t kSmallBatch = 32;        // batches up to this size take the copy-free path of cph_search / cph_search_batch
 
 struct cph_index {
     uint64_t dim = 0;
@@ -164,8 +170,8 @@ void require_finalized(cph_index* h) {
 }
 
 void release_scratch(BatchSet& s) {
-    s.d_bitmaps.release(); s.d_logids.release(); s.d_beam.release();
-    s.r_bitmaps.release(); s.r_logids.release(); s.r_beam.release();
+    s.d_bitmaps.release(); s.d_logids.release(); s.d_beam.release(); s.d_beam_tail.release();
+    s.r_bitmaps.release(); s.r_logids.release(); s.r_beam.release(); s.r_beam_tail.release();
     s.slots = 0; s.cap = 0; s.r_slots = 0;
 }
 
@@ -372,7 +378,8 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
         s.d_bitmaps.alloc((size_t)slots * bm_words);
         HIP_CHECK(hipMemsetAsync(s.d_bitmaps.p, 0, (size_t)slots * bm_words * 4, st));
         s.d_logids.alloc((size_t)slots * cap);
-        s.d_beam.alloc((size_t)slots * beam_slot_dwords(cap));
+        s.d_beam.alloc((size_t)slots * kBeamPagesDwords);
+        s.d_beam_tail.alloc((size_t)slots * beam_tail_dwords(cap));
         s.slots = slots;
         s.cap = cap;
     }
@@ -380,18 +387,21 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
     if (cap < n + 1 && s.r_slots == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t per = (n + 1) * 4 + beam_slot_dwords(n + 1) * 4 + bm_words * 4;
+        const uint64_t per = (n + 1) * 4 + ((uint64_t)kBeamPagesDwords + beam_tail_dwords(n + 1)) * 4 + bm_words * 4;
         const uint32_t rs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (uint64_t)(free_b * 0.25) / per));
         s.r_bitmaps.alloc((size_t)rs * bm_words);
         HIP_CHECK(hipMemsetAsync(s.r_bitmaps.p, 0, (size_t)rs * bm_words * 4, st));
         s.r_logids.alloc((size_t)rs * (n + 1));
-        s.r_beam.alloc((size_t)rs * beam_slot_dwords(n + 1));
+        s.r_beam.alloc((size_t)rs * kBeamPagesDwords);
+        s.r_beam_tail.alloc((size_t)rs * beam_tail_dwords(n + 1));
         s.r_slots = rs;
     }
 }
 
-void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                   const uint32_t* d_todo, bool rerun, hipStream_t st) {
+// mode 0: the batch on the set's slots (capacity s.cap); 1: the overflow re-run on the full-capacity slots (its list of
+// queries lives on the device); 2: a batch small enough for the full-capacity slots, run there directly (no re-run needed)
+void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist, uint32_t* d_count,
+                   const uint32_t* d_todo, int mode, hipStream_t st) {
     SearchArgs a{};
     a.blocks = h->d_blocks.p;
     a.raw = h->d_raw.p;
@@ -407,32 +417,34 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     a.bm_words = (h->host.n + 31) / 32;
     a.out_ids = d_ids;
     a.out_dist = d_dist;
-    a.out_count = s.d_count.p;
+    a.out_count = d_count;
     a.status = s.d_status.p;
     a.stats = s.d_stats.p;
     uint32_t* words = reinterpret_cast<uint32_t*>(s.d_stats.p + 16);   // [0] queue, [1] re-run list length, [2] re-run queue
     uint32_t grid;
-    if (!rerun) {
+    if (mode == 0) {
         a.todo = d_todo;
         a.nq = nq;
         a.counter = words;
         a.cap = s.cap;
         a.bitmaps = s.d_bitmaps.p;
-        a.beam = s.d_beam.p;
+        a.beam_pages = s.d_beam.p;
+        a.beam_tail = s.d_beam_tail.p;
         a.log_ids = s.d_logids.p;
         a.redo = s.cap < h->host.n + 1 ? s.d_redo.p : nullptr;
         a.redo_count = words + 1;
         grid = s.run_slots;
     } else {
-        a.todo = s.d_redo.p;
-        a.nq = 0;
-        a.nq_dev = words + 1;
-        a.counter = words + 2;
+        a.todo = mode == 1 ? s.d_redo.p : nullptr;
+        a.nq = mode == 1 ? 0 : nq;
+        a.nq_dev = mode == 1 ? words + 1 : nullptr;
+        a.counter = mode == 1 ? words + 2 : words;
         a.cap = h->host.n + 1;
         a.bitmaps = s.r_bitmaps.p;
-        a.beam = s.r_beam.p;
+        a.beam_pages = s.r_beam.p;
+        a.beam_tail = s.r_beam_tail.p;
         a.log_ids = s.r_logids.p;
-        grid = s.r_slots;
+        grid = mode == 1 ? s.r_slots : nq;
     }
     const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
     if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
@@ -443,7 +455,7 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
 // `st` and nothing waits for the device: a query that outgrows its scratch is answered by the
 // full-capacity re-run launch that always follows the main one (it finds an empty list otherwise).
 void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                    hipStream_t st) {
+                    hipStream_t st, uint32_t* d_count_out = nullptr) {
     const uint64_t n = h->host.n;
     if (s.d_count.n < nq) {
         if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
@@ -484,7 +496,7 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         // budget: at most 30% of what is free (plus what this set already holds) -- there are two sets
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        auto slot_bytes = [&](uint64_t c) { return c * 4 + (uint64_t)beam_slot_dwords(c) * 4 + bm_bytes; };   // id log + beam spill + bitmap
+        auto slot_bytes = [&](uint64_t c) { return c * 4 + ((uint64_t)kBeamPagesDwords + beam_tail_dwords(c)) * 4 + bm_bytes; };   // id log + beam spill + bitmap
         const uint64_t held = (uint64_t)s.slots * slot_bytes(s.cap);
         const uint64_t budget = (uint64_t)((free_b + held) * 0.3);
         while (slots > 64 && (uint64_t)slots * slot_bytes(cap) > budget) slots /= 2;
@@ -501,9 +513,16 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         HIP_CHECK(hipGetLastError());
         d_order = s.d_order.p;
     }
+    uint32_t* d_count = d_count_out ? d_count_out : s.d_count.p;
     HIP_CHECK(hipEventRecord(s.ev0, st));
-    launch_search(h, s, nq, k, d_ids, d_dist, d_order, false, st);
-    if (s.cap < n + 1) launch_search(h, s, nq, k, d_ids, d_dist, nullptr, true, st);
+    if (s.cap < n + 1 && nq <= s.r_slots) {
+        // a handful of queries: straight onto the full-capacity slots -- one launch, nothing can overflow
+        s.run_slots = nq;
+        launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 2, st);
+    } else {
+        launch_search(h, s, nq, k, d_ids, d_dist, d_count, d_order, 0, st);
+        if (s.cap < n + 1) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st);
+    }
     HIP_CHECK(hipEventRecord(s.ev1, st));
     // the statistics block lands in pinned host memory; it is only read when somebody asks
     HIP_CHECK(hipMemcpyAsync(s.pin_stats, s.d_stats.p, kStatWords * 8, hipMemcpyDeviceToHost, st));
@@ -515,6 +534,33 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
 hipStream_t own_stream(cph_index* h) {
     if (!h->own_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     return h->own_stream;
+}
+
+// Views into a set's pinned, device-mapped I/O buffer for a batch of `n` queries: [ids n*k*8 | dist n*k*4 | counts n*4 |
+// queries n*dim*4], host and device addresses of the same bytes.
+struct SmallIo {
+    int64_t* h_ids; float* h_dist; uint32_t* h_count; float* h_query;
+    int64_t* d_ids; float* d_dist; uint32_t* d_count; const float* d_query;
+};
+SmallIo small_io(cph_index* h, BatchSet& s, uint64_t n, uint64_t k) {
+    const size_t o_dist = n * k * 8, o_cnt = o_dist + n * k * 4, o_q = (o_cnt + n * 4 + 15) & ~(size_t)15;
+    const size_t need = o_q + n * h->dim * 4;
+    if (s.pin_io_bytes < need) {
+        if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
+        if (s.pin_io) HIP_CHECK(hipHostFree(s.pin_io));
+        s.pin_io = nullptr;
+        s.pin_io_bytes = 0;
+        const size_t bytes = std::max<size_t>(need * 2, 64 * 1024);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.pin_io), bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.pin_io_dev), s.pin_io, 0));
+        s.pin_io_bytes = bytes;
+    }
+    uint8_t* hb = s.pin_io;
+    uint8_t* db = s.pin_io_dev;
+    return SmallIo{reinterpret_cast<int64_t*>(hb), reinterpret_cast<float*>(hb + o_dist), reinterpret_cast<uint32_t*>(hb + o_cnt),
+                   reinterpret_cast<float*>(hb + o_q),
+                   reinterpret_cast<int64_t*>(db), reinterpret_cast<float*>(db + o_dist), reinterpret_cast<uint32_t*>(db + o_cnt),
+                   reinterpret_cast<const float*>(db + o_q)};
 }
 
 }  // namespace
@@ -573,6 +619,7 @@ int cph_destroy(cph_index* h) {
             if (s.ev1) (void)hipEventDestroy(s.ev1);
             if (s.ev_done) (void)hipEventDestroy(s.ev_done);
             if (s.pin_stats) (void)hipHostFree(s.pin_stats);
+            if (s.pin_io) (void)hipHostFree(s.pin_io);
         }
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
         delete h;
@@ -779,13 +826,13 @@ int cph_debug_heap_ops(int device, const uint8_t* ops, uint64_t n_ops, const flo
         DevBuf<uint8_t> d_ops(n_ops);
         DevBuf<float> d_keys(std::max<uint64_t>(1, n_push)), d_ok(std::max<uint64_t>(1, n_push));
         DevBuf<uint32_t> d_ids(std::max<uint64_t>(1, n_push)), d_oi(std::max<uint64_t>(1, n_push)), d_sz(1);
-        DevBuf<uint32_t> d_spill(beam_slot_dwords(std::max<uint64_t>(1, n_push) + 64));
+        DevBuf<uint32_t> d_spill(kBeamPagesDwords), d_spill_tail(beam_tail_dwords(std::max<uint64_t>(1, n_push) + 64));
         HIP_CHECK(hipMemcpy(d_ops.p, ops, n_ops, hipMemcpyHostToDevice));
         if (n_push) {
             HIP_CHECK(hipMemcpy(d_keys.p, keys, n_push * 4, hipMemcpyHostToDevice));
             HIP_CHECK(hipMemcpy(d_ids.p, ids, n_push * 4, hipMemcpyHostToDevice));
         }
-        HeapTestArgs a{d_ops.p, d_keys.p, d_ids.p, (uint32_t)n_ops, d_spill.p, d_ok.p, d_oi.p, d_sz.p};
+        HeapTestArgs a{d_ops.p, d_keys.p, d_ids.p, (uint32_t)n_ops, d_spill.p, d_spill_tail.p, d_ok.p, d_oi.p, d_sz.p};
         hipLaunchKernelGGL(heap_selftest_kernel, dim3(1), dim3(64), 0, nullptr, a);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
@@ -1014,6 +1061,17 @@ int cph_search_batch(cph_index* h, const float* queries, uint64_t n, uint64_t k,
         h->use_device();
         hipStream_t st = own_stream(h);
         BatchSet& s = next_set(h, st);
+        if (n <= kSmallBatch && n * k <= (1u << 20)) {
+            // a handful of queries: no copy commands, the kernels read the queries and write the results over PCIe
+            SmallIo io = small_io(h, s, n, k);
+            std::memcpy(io.h_query, queries, n * h->dim * sizeof(float));
+            stage_queries(h, s, io.d_query, n, st);
+            enqueue_search(h, s, (uint32_t)n, (uint32_t)k, io.d_ids, io.d_dist, st, io.d_count);
+            HIP_CHECK(hipStreamSynchronize(st));
+            std::memcpy(ids, io.h_ids, n * k * 8);
+            std::memcpy(dist, io.h_dist, n * k * 4);
+            return;
+        }
         stage_queries(h, s, upload_queries(h, s, queries, n, st), n, st);
         if (s.d_ids.n < n * k) {
             if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
@@ -1056,20 +1114,15 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
         h->use_device();
         hipStream_t st = own_stream(h);
         BatchSet& s = next_set(h, st);
-        stage_queries(h, s, upload_queries(h, s, query, 1, st), 1, st);
-        if (s.d_ids.n < kk) {
-            if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
-            s.d_ids.alloc(kk);
-            s.d_dist.alloc(kk);
-        }
-        enqueue_search(h, s, 1, (uint32_t)kk, s.d_ids.p, s.d_dist.p, st);
+        SmallIo io = small_io(h, s, 1, kk);
+        std::memcpy(io.h_query, query, h->dim * sizeof(float));
+        stage_queries(h, s, io.d_query, 1, st);                       // the encoder reads the query over PCIe
+        enqueue_search(h, s, 1, (uint32_t)kk, io.d_ids, io.d_dist, st, io.d_count);   // ... the search writes the results back
         HIP_CHECK(hipStreamSynchronize(st));
-        uint32_t cnt = 0;
-        HIP_CHECK(hipMemcpy(&cnt, s.d_count.p, 4, hipMemcpyDeviceToHost));
-        // the reference returns every result it found (<= max(k,1)); the caller's buffers
-        // hold max(k,1) entries
-        HIP_CHECK(hipMemcpy(ids, s.d_ids.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(dist, s.d_dist.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        // the reference returns every result it found (<= max(k,1)); the caller's buffers hold max(k,1) entries
+        const uint32_t cnt = io.h_count[0];
+        std::memcpy(ids, io.h_ids, (size_t)cnt * 8);
+        std::memcpy(dist, io.h_dist, (size_t)cnt * 4);
         *m = cnt;
     });
 }

@@ -16,7 +16,8 @@ struct HeapTestArgs {
     const float* keys;       // [pushes]
     const uint32_t* ids;     // [pushes]
     uint32_t n_ops;
-    uint32_t* spill;         // [beam_slot_dwords(cap)] HBM part of the heap (beam_off)
+    uint32_t* pages;         // [kBeamPagesDwords] HBM part of the heap, levels 8..12
+    uint32_t* tail;          // [beam_tail_dwords(cap)] levels 13+
     float* out_keys;         // [final size]
     uint32_t* out_ids;
     uint32_t* out_size;
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(64) void heap_selftest_kernel(HeapTestArgs a) {
     const int lane = threadIdx.x;
     Beam heap;
     heap.l = (lds_u32x4*)lds;
-    heap.g = a.spill;
+    heap.gp = a.pages;
+    heap.gt = a.tail;
     uint32_t size = 0, next = 0;
     for (uint32_t j = 0; j < a.n_ops; ++j) {
         if (a.ops[j]) {

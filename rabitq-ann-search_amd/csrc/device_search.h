@@ -56,7 +56,8 @@ struct SearchArgs {
     uint64_t cap;           // per-slot log/heap capacity
     uint64_t bm_words;      // per-slot bitmap words
     uint32_t* bitmaps;
-    uint32_t* beam;         // beam heap beyond the LDS-resident top levels: beam_slot_dwords(cap) per slot (beam_off)
+    uint32_t* beam_pages;   // beam heap levels 8..12: kBeamPagesDwords per slot (beam_page_off)
+    uint32_t* beam_tail;    // beam heap levels 13+: beam_tail_dwords(cap) per slot (beam_tail_off)
     uint32_t* log_ids;      // every newly estimated id, in discovery order (for un-marking)
     // outputs
     int64_t* out_ids;       // [nq][k]
@@ -155,10 +156,13 @@ __device__ __forceinline__ void nn_sort(Result* h, uint32_t size) {  // std::sor
 constexpr uint32_t kBeamLds = 255;                    // 8 full levels, 16 B per entry
 constexpr uint32_t kBeamPaged = 8191;                 // heap indices below this and >= kBeamLds live in pages
 constexpr uint32_t kPageDwords = 192;                 // 64 entries x 3 dwords
-constexpr uint32_t kBeamTail = 128 * kPageDwords;     // dword offset of heap index kBeamPaged
-// dwords of one slot's spill area for a beam of at most `cap` entries (a multiple of 32: slots start on a line)
-__host__ __device__ inline size_t beam_slot_dwords(uint64_t cap) {
-    const size_t d = kBeamTail + 3 * (size_t)(cap > kBeamPaged ? cap - kBeamPaged : 0) + 4;
+constexpr uint32_t kBeamPagesDwords = 128 * kPageDwords;   // one slot's pages: 96 KB
+// The pages and the tails are two arrays: [slot][pages] is what spilled beams actually touch (a beam of the recall
+// workload holds ~5,000 entries, 13,800 at most), dense -- 96 KB per slot, 600 MB for 6,144 slots -- instead of 96 KB
+// at the head of every slot's (cap x 12 B)-sized region, i.e. one 2-MB translation per slot; the tails (heap indices
+// >= 8191, sized by `cap`) are rarely touched.
+__host__ __device__ inline size_t beam_tail_dwords(uint64_t cap) {   // per slot, a multiple of 32
+    const size_t d = 3 * (size_t)(cap > kBeamPaged ? cap - kBeamPaged : 0) + 4;
     return (d + 31) & ~(size_t)31;
 }
 
@@ -174,19 +178,21 @@ typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) float lds_f32;
 
-// dword offset of heap index i >= kBeamLds inside the slot's spill area
-__device__ __forceinline__ uint32_t beam_spill_off(uint32_t i) {
+// dword offset of heap index i (kBeamLds <= i < kBeamPaged) inside the slot's pages
+__device__ __forceinline__ uint32_t beam_page_off(uint32_t i) {
     const uint32_t hp = i + 1;
-    const uint32_t l = (31u - (uint32_t)__builtin_clz(hp)) - 7u;              // levels below the LDS part: 1..5 in the pages
-    const uint32_t r = (hp & ((1u << (l & 7u)) - 1u)) | (1u << (l & 7u));     // index inside the level-7 node's subtree
-    const uint32_t paged = ((hp >> (l & 7u)) - 128u) * kPageDwords + 3u * r;
-    return hp < kBeamPaged + 1 ? paged : kBeamTail + 3u * (hp - (kBeamPaged + 1));
+    const uint32_t l = ((31u - (uint32_t)__builtin_clz(hp)) - 7u) & 7u;       // levels below the LDS part: 1..5
+    const uint32_t r = (hp & ((1u << l) - 1u)) | (1u << l);                   // index inside the level-7 node's subtree
+    return ((hp >> l) - 128u) * kPageDwords + 3u * r;
 }
+// dword offset of heap index i >= kBeamPaged inside the slot's tail
+__device__ __forceinline__ uint32_t beam_tail_off(uint32_t i) { return 3u * (i - kBeamPaged); }
 
 struct Beam {
     typedef uint4 E;
     lds_u32x4* l;   // LDS, [kBeamLds + 1]   {est bits, lower bits, id, -}
-    uint32_t* g;    // global, the slot's spill area (beam_off)
+    uint32_t* gp;   // global, the slot's pages (beam_page_off)
+    uint32_t* gt;   // global, the slot's tail (beam_tail_off)
     // the heap's comparator (std::greater on est: a min-heap) and the key of an entry
     static __device__ __forceinline__ bool before(float a, float b) { return a > b; }
     static __device__ __forceinline__ float key_of(uint4 e) { return __uint_as_float(e.x); }
@@ -202,27 +208,34 @@ struct Beam {
     __device__ __forceinline__ float lds_key(uint32_t i) const {
         return reinterpret_cast<lds_f32*>(l)[4 * i];
     }
-    // one 12-byte entry of the spill area (dword offset)
-    __device__ __forceinline__ uint4 gload(uint32_t off) const {
-        const u32x3 t = *reinterpret_cast<const u32x3 __attribute__((aligned(4)))*>(g + off);
+    // one 12-byte entry at a dword offset of the pages / of the tail
+    static __device__ __forceinline__ uint4 load3(const uint32_t* p) {
+        const u32x3 t = *reinterpret_cast<const u32x3 __attribute__((aligned(4)))*>(p);
         return make_uint4(t.x, t.y, t.z, 0u);
     }
-    __device__ __forceinline__ void gstore(uint32_t off, uint4 v) const {
+    static __device__ __forceinline__ void store3(uint32_t* p, uint4 v) {
         u32x3 t;
         t.x = v.x; t.y = v.y; t.z = v.z;
-        *reinterpret_cast<u32x3 __attribute__((aligned(4)))*>(g + off) = t;
+        *reinterpret_cast<u32x3 __attribute__((aligned(4)))*>(p) = t;
+    }
+    __device__ __forceinline__ uint4 pload(uint32_t off) const { return load3(gp + off); }
+    __device__ __forceinline__ void pstore(uint32_t off, uint4 v) const { store3(gp + off, v); }
+    __device__ __forceinline__ uint4 tload(uint32_t off) const { return load3(gt + off); }
+    __device__ __forceinline__ void tstore(uint32_t off, uint4 v) const { store3(gt + off, v); }
+    __device__ __forceinline__ uint32_t* spill_ptr(uint32_t i) const {       // i >= kBeamLds
+        return i < kBeamPaged ? gp + beam_page_off(i) : gt + beam_tail_off(i);
     }
     __device__ __forceinline__ uint4 raw(uint32_t i) const {
         uint4 v;
-        if (i < kBeamLds) v = lds(i); else v = gload(beam_spill_off(i));
+        if (i < kBeamLds) v = lds(i); else v = load3(spill_ptr(i));
         return v;
     }
     __device__ __forceinline__ void put(uint32_t i, uint4 v) const {
-        if (i < kBeamLds) lds_put(i, v); else gstore(beam_spill_off(i), v);
+        if (i < kBeamLds) lds_put(i, v); else store3(spill_ptr(i), v);
     }
     __device__ __forceinline__ float raw_key(uint32_t i) const {
         float k;
-        if (i < kBeamLds) k = lds_key(i); else k = __uint_as_float(g[beam_spill_off(i)]);
+        if (i < kBeamLds) k = lds_key(i); else k = __uint_as_float(*spill_ptr(i));
         return k;
     }
     __device__ __forceinline__ BeamEntry get(uint32_t i) const {
@@ -272,8 +285,11 @@ __device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lan
     const uint32_t len = size - 1;                // heap length once the last element is taken out
     const typename H::E v = h.lds(len);            // the value __adjust_heap re-inserts
     const uint32_t nint = (len - 1) >> 1;         // nodes j < nint have both children below len
-    bool b0 = false, b1 = false;                  // true: the left child moves up
-    if ((uint32_t)lane < nint) b0 = H::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1));
+    // true: the left child moves up.  (Read by every lane -- entries up to index 128 / 256 exist in LDS whatever the heap
+    // holds -- and masked afterwards: a predicated read costs an exec-mask save / restore, and the scalar unit is what
+    // this kernel runs out of.)
+    const bool b0 = H::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1)) && (uint32_t)lane < nint;
+    bool b1 = false;
     const unsigned long long m0 = __ballot(b0);
     unsigned long long m1 = 0;
     if (nint > 64) {
@@ -285,37 +301,33 @@ __device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lan
     // the path is a prefix of it -- p_t = (hp >> (d - t)) - 1.  The loop is scalar-only; each lane
     // then derives its own pair of path positions with two shifts.
     uint32_t hp = 1, d = 0;
-    if (nint <= 63) {
-        // The usual case, four scalar instructions per level: with the mask shifted up by one, node hp - 1's
-        // bit sits at position hp; s_bitcmp0 puts "the right child moves up" into SCC and s_addc turns
-        // hp into 2 hp + SCC.  The depth is recovered from hp's leading one afterwards.
-        if (nint >= 1) {
-            const unsigned long long ms = m0 << 1;
+    if (nint >= 1) {
+        // Scalar walk, four instructions per level: with the mask shifted up by one, node hp - 1's bit sits at position
+        // hp; s_bitcmp0 puts "the right child moves up" into SCC and s_addc turns hp into 2 hp + SCC.  Nodes 63..126
+        // (hp = 64..127: at most the last step of a heap of up to 255 entries) take their bit from a second mask at
+        // position hp - 64, which is hp's low six bits -- all the instruction looks at.  The depth is recovered from
+        // hp's leading one afterwards.
+        const unsigned long long ms0 = m0 << 1;
+        const uint32_t lim = nint < 63u ? nint : 63u;
+        asm volatile(
+            "1:\n\t"
+            "s_bitcmp0_b64 %[m], %[hp]\n\t"
+            "s_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_cmp_le_u32 %[hp], %[n]\n\t"
+            "s_cbranch_scc1 1b"
+            : [hp] "+s"(hp)
+            : [m] "s"(ms0), [n] "s"(lim)
+            : "scc");
+        if (hp <= nint) {                          // 64 <= hp <= 126
+            const unsigned long long ms1 = (m1 << 1) | (m0 >> 63);
             asm volatile(
-                "1:\n\t"
                 "s_bitcmp0_b64 %[m], %[hp]\n\t"
-                "s_addc_u32 %[hp], %[hp], %[hp]\n\t"
-                "s_cmp_le_u32 %[hp], %[n]\n\t"
-                "s_cbranch_scc1 1b"
+                "s_addc_u32 %[hp], %[hp], %[hp]"
                 : [hp] "+s"(hp)
-                : [m] "s"(ms), [n] "s"(nint)
+                : [m] "s"(ms1)
                 : "scc");
-            d = 31u - (uint32_t)__builtin_clz(hp);
         }
-    } else if (nint <= 64) {                       // one mask, but node 63's bit does not survive the shift
-        while (hp - 1 < nint) {
-            const uint32_t left = (uint32_t)(m0 >> (hp - 1)) & 1u;
-            hp = 2 * hp + 1 - left;
-            ++d;
-        }
-    } else {
-        while (hp - 1 < nint) {
-            const uint32_t hole = hp - 1;
-            const unsigned long long m = hole < 64 ? m0 : m1;
-            const uint32_t left = (uint32_t)(m >> (hole & 63)) & 1u;
-            hp = 2 * hp + 1 - left;
-            ++d;
-        }
+        d = 31u - (uint32_t)__builtin_clz(hp);
     }
     if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
         hp = 2 * hp;
@@ -325,17 +337,16 @@ __device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lan
     const uint32_t t = (uint32_t)lane < d ? (uint32_t)lane : 0u;
     const uint32_t my_dst = (hp >> (d - t)) - 1;                    // p_t: lane t moves entry p_{t+1} into it
     const uint32_t my_src = (hp >> (d - t - ((uint32_t)lane < d ? 1u : 0u))) - 1;   // p_{t+1}
-    typename H::E e = v;
-    bool c = false;                                // __push_heap: parent (now e_t) > v -> parent moves down
-    if ((uint32_t)lane < d) {
-        e = h.lds(my_src);
-        c = H::before(H::key_of(e), H::key_of(v));
-    }
+    // __push_heap: parent (now e_t) > v -> parent moves down.  Lanes >= d read p_1 (t = 0) and are masked out below.
+    const typename H::E e = h.lds(my_src);
+    const bool c = H::before(H::key_of(e), H::key_of(v));
     const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
     const uint32_t fin = stay ? 64u - (uint32_t)__builtin_clzll(stay) : 0u;   // v ends at p_fin
     if ((uint32_t)lane < fin) h.lds_put(my_dst, e);
-    if (fin == d) { if (lane == 0) h.lds_put(hole, v); }
-    else if ((uint32_t)lane == fin) h.lds_put(my_dst, v);
+    // p_fin = (hp >> (d - fin)) - 1 for every fin (= the hole when fin == d): one writer, one wave-uniform address, behind
+    // the moves in program order (lane 0's own move, if any, went to p_0 != p_fin)
+    if (lane == 0) h.lds_put((hp >> (d - fin)) - 1, v);
+    (void)hole;
 }
 
 // std::push_heap of `v` at index `hole` (= the heap's size before the push) for a beam that stays inside the LDS
@@ -351,12 +362,8 @@ __device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typena
     const uint32_t t = (uint32_t)lane + 1;                              // lane t - 1 looks at ancestor p_t
     const bool on = t <= depth;
     const uint32_t pt = on ? (hp >> t) - 1 : 0u;
-    typename H::E e = v;
-    bool down = false;
-    if (on) {
-        e = h.lds(pt);
-        down = H::before(H::key_of(e), H::key_of(v));
-    }
+    const typename H::E e = h.lds(pt);                                 // (lanes past the root read it again and are masked)
+    const bool down = on && H::before(H::key_of(e), H::key_of(v));
     const unsigned long long stop = ~__ballot(down);                   // first ancestor that stays (bits >= depth are set)
     const uint32_t m = (uint32_t)__builtin_ctzll(stop);                 // ancestors p_1..p_m move down
     if (t <= m) h.lds_put((hp >> (t - 1)) - 1, e);                      // p_t's entry to p_(t-1), p_0 = the leaf
@@ -377,7 +384,7 @@ __device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typena
 // order + a dependent read of the path (round 2) 216 ms; pages (round 3): see DESIGN.md section 6.
 __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, int lane) {
     const uint32_t len = size - 1;                 // >= kBeamLds: the last element lives in HBM
-    const uint4 v = h.gload(beam_spill_off(len));        // the value __adjust_heap re-inserts (same address in every lane)
+    const uint4 v = Beam::load3(h.spill_ptr(len));       // the value __adjust_heap re-inserts (same address in every lane)
     // LDS levels 0..6: nodes 0..126, both children always inside the LDS part
     const bool b0 = Beam::before(h.lds_key(2 * lane + 2), h.lds_key(2 * lane + 1));
     const unsigned long long m0 = __ballot(b0);
@@ -385,28 +392,48 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
     if (lane < 63) b1 = Beam::before(h.lds_key(2 * lane + 130), h.lds_key(2 * lane + 129));
     const unsigned long long m1 = __ballot(b1);
     uint32_t hp = 1, d = 7;                        // hp = hole + 1, the path as a bit string (see heap_pop_wave)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const uint32_t hole = hp - 1;
-        const unsigned long long m = hole < 64 ? m0 : m1;
-        hp = 2 * hp + 1 - ((uint32_t)(m >> (hole & 63)) & 1u);
+    {
+        // seven steps, two scalar instructions each (heap_pop_wave's walk, unrolled: every node of levels 0..6 has both
+        // children); the last one reads nodes 63..126 from the second mask at position hp - 64 = hp's low six bits
+        const unsigned long long ms0 = m0 << 1, ms1 = (m1 << 1) | (m0 >> 63);
+        asm volatile(
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[a], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]\n\t"
+            "s_bitcmp0_b64 %[b], %[hp]\n\ts_addc_u32 %[hp], %[hp], %[hp]"
+            : [hp] "+s"(hp)
+            : [a] "s"(ms0), [b] "s"(ms1)
+            : "scc");
     }
     // relative node of this lane inside a five-level window: 1-based, the window's root = 1, lanes 0..61 hold 2..63
     const uint32_t r = (uint32_t)lane + 2;
     const uint32_t dr = 31u - (uint32_t)__builtin_clz(r);
-    // one window: E2 = pairs of children that both exist, M = "the left child moves up"; walks up to five levels
+    // one window: E2 = pairs of children that both exist, M = "the left child moves up"; walks up to five levels.
+    // The pair under relative node P sits in lanes 2P - 2 and 2P - 1; with both masks shifted up by two its bit is at
+    // position 2P: per level s_lshl (2P), s_bitcmp1 (does the pair exist), branch, s_bitcmp0 + s_addc (P <- 2P + "right").
     auto walk = [&](float key, uint32_t idx) {
         const float key_r = __shfl_down(key, 1);   // even lanes hold left children, their right siblings sit one lane up
         const bool both = (lane & 1) == 0 && lane < 62 && idx + 1 < len;
-        const unsigned long long E2 = __ballot(both);
-        const unsigned long long M = __ballot(both && Beam::before(key_r, key));
-        uint32_t P = 1, steps = 0;
-        while (steps < 5) {
-            const uint32_t bit = 2 * P - 2;        // the pair under relative node P sits in lanes 2P-2, 2P-1
-            if (!((E2 >> bit) & 1ull)) break;
-            P = 2 * P + 1 - ((uint32_t)(M >> bit) & 1u);
-            ++steps;
-        }
+        const unsigned long long E2 = __ballot(both) << 2;
+        const unsigned long long M = __ballot(both && Beam::before(key_r, key)) << 2;
+        uint32_t P = 1, tmp;
+        asm volatile(
+            "1:\n\t"
+            "s_lshl_b32 %[t], %[P], 1\n\t"
+            "s_bitcmp1_b64 %[e], %[t]\n\t"
+            "s_cbranch_scc0 2f\n\t"
+            "s_bitcmp0_b64 %[m], %[t]\n\t"
+            "s_addc_u32 %[P], %[P], %[P]\n\t"
+            "s_cmp_lt_u32 %[P], 32\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:"
+            : [P] "+s"(P), [t] "=&s"(tmp)
+            : [e] "s"(E2), [m] "s"(M)
+            : "scc");
+        const uint32_t steps = 31u - (uint32_t)__builtin_clz(P);
         hp = (hp << steps) | (P & ((1u << steps) - 1u));
         d += steps;
         return steps;
@@ -418,14 +445,14 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
     uint32_t steps = 0;
     if (2 * hp - 1 < len) {
         const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
-        if (lane < 62 && idx < len) w = h.gload(pbase + 3u * r);
+        if (lane < 62 && idx < len) w = h.pload(pbase + 3u * r);
         steps = walk(__uint_as_float(w.x), idx);
     }
     // levels 13+: windows of keys over the heap-ordered tail
     while (steps == 5 && 2 * hp < len) {
         const uint32_t idx = ((hp << dr) | (r & ((1u << dr) - 1u))) - 1u;
         float key = 0.0f;
-        if (lane < 62 && idx < len) key = __uint_as_float(h.g[kBeamTail + 3u * (idx - kBeamPaged)]);
+        if (lane < 62 && idx < len) key = __uint_as_float(h.gt[beam_tail_off(idx)]);
         steps = walk(key, idx);
     }
     if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
@@ -443,8 +470,8 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
     };
     auto put_level = [&](uint32_t level, uint32_t node_hp, uint4 val) {
         if (level <= 7) h.lds_put(node_hp - 1, val);
-        else if (level <= 12) h.gstore(pbase + 3u * page_rel(node_hp, level - 7u), val);
-        else h.gstore(kBeamTail + 3u * (node_hp - (kBeamPaged + 1)), val);
+        else if (level <= 12) h.pstore(pbase + 3u * page_rel(node_hp, level - 7u), val);
+        else h.tstore(beam_tail_off(node_hp - 1), val);
     };
     // sources on levels 8..12 come out of the window lane that read them: relative node -> lane r - 2
     const bool from_page = (uint32_t)lane < d && t >= 7 && t <= 11;
@@ -456,7 +483,7 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
     if ((uint32_t)lane < d) {
         if (t < 7) e = h.lds(src_hp - 1);
         else if (t <= 11) e = pw;
-        else e = h.gload(kBeamTail + 3u * (src_hp - (kBeamPaged + 1)));
+        else e = h.tload(beam_tail_off(src_hp - 1));
         c = Beam::before(Beam::key_of(e), Beam::key_of(v));
     }
     const unsigned long long stay = ~__ballot(c) & ((1ull << d) - 1ull);
@@ -482,13 +509,13 @@ __device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, u
         const uint32_t rl = (hp & ((1u << lvl) - 1u)) | (1u << lvl);           // the leaf's relative index in its page
         // ancestor p_t sits on level depth - t: in the page while t < lvl (relative index rl >> t), in LDS above
         if (on) {
-            if (t < lvl) e = h.gload(pbase + 3u * (rl >> t)); else e = h.lds((hp >> t) - 1);
+            if (t < lvl) e = h.pload(pbase + 3u * (rl >> t)); else e = h.lds((hp >> t) - 1);
             down = Beam::before(Beam::key_of(e), Beam::key_of(v));
         }
         const unsigned long long stop = ~__ballot(down);
         const uint32_t m = (uint32_t)__builtin_ctzll(stop);
         auto put_anc = [&](uint32_t s, uint4 val) {                            // ancestor p_s (s = 0: the leaf)
-            if (s < lvl) h.gstore(pbase + 3u * (rl >> s), val); else h.lds_put((hp >> s) - 1, val);
+            if (s < lvl) h.pstore(pbase + 3u * (rl >> s), val); else h.lds_put((hp >> s) - 1, val);
         };
         if (t <= m) put_anc(t - 1, e);
         if ((uint32_t)lane == m) put_anc(m, v);
@@ -622,7 +649,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
     uint32_t* logi = CPH_COLD(log_ids) + (size_t)slot * a.cap;
     Beam heap;
     heap.l = s_beam;
-    heap.g = CPH_COLD(beam) + (size_t)slot * beam_slot_dwords(a.cap);
+    heap.gp = CPH_COLD(beam_pages) + (size_t)slot * kBeamPagesDwords;
+    heap.gt = CPH_COLD(beam_tail) + (size_t)slot * beam_tail_dwords(a.cap);
     const float FMAX = 3.402823466e+38f;
     if (lane < kMaxSlack) s_slack[lane] = a.sc.slack[lane];
 
@@ -801,7 +829,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 const uint32_t sh = on ? depth - 7u - j : 0u;
                 const uint32_t rj = ((beam_size >> sh) & ((1u << (j & 7u)) - 1u)) | (1u << (j & 7u));
                 const uint32_t pb = ((beam_size >> (depth - 7u)) - 128u) * kPageDwords;
-                touch = heap.g[on ? pb + 3u * rj : 0u];
+                touch = heap.gp[on ? pb + 3u * rj : 0u];
             }
             pop_beam(beam_size);
             --beam_size;
@@ -826,7 +854,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // no return value.  (A test-and-set for all 32 made the L2 atomic units the bottleneck.)
             uint32_t old_bits = 0;
             const uint32_t my_bit = 1u << (nid & 31);
-            if (active) old_bits = __hip_atomic_load(&bm[nid >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (every lane loads -- the upper half and empty slots read word 0 -- instead of a predicated load: one select
+            // against an exec-mask save / branch / restore on the scalar unit)
+            old_bits = __hip_atomic_load(&bm[active ? nid >> 5 : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
 #ifdef CPH_TRAFFIC_STATS
             {   // distinct 128-byte lines of the bitmap this probe touches
@@ -883,8 +913,16 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     if (nj && lane > j && lane < 32 && oj == nid) is_new = false;
                 }
             }
-            if (is_new) atomicOr(&bm[nid >> 5], my_bit);   // mark (two new ids may share a word)
             const uint32_t new_mask = (uint32_t)(__ballot(is_new) & 0xFFFFFFFFull);
+            // mark the new ids (two may share a word) and log them for the un-marking at query end (discovery order =
+            // neighbour order) under ONE predicate; a log that would overflow ends the attempt before anything is marked
+            const uint32_t n_new = __popc(new_mask);
+            const uint32_t my_rank = __builtin_amdgcn_mbcnt_lo(new_mask, 0u);   // set bits below this lane (lanes < 32)
+            if (log_count + n_new > a.cap) { overflow = true; break; }
+            if (is_new) {
+                atomicOr(&bm[nid >> 5], my_bit);
+                logi[log_count + my_rank] = nid;
+            }
             // slack level schedule (:141-145)
             if (a.sc.num_slack > 0) {
                 int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
@@ -929,11 +967,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             bool cand = is_new && (warmup || (!(lower >= worst0) && est < worst0));
             const uint32_t cand_mask = (uint32_t)(__ballot(cand) & 0xFFFFFFFFull);
 
-            // log new ids (discovery order = neighbour order)
-            const uint32_t n_new = __popc(new_mask);
-            const uint32_t my_rank = __builtin_amdgcn_mbcnt_lo(new_mask, 0u);   // set bits below this lane (lanes < 32)
-            if (log_count + n_new > a.cap) { overflow = true; break; }
-            if (is_new) logi[log_count + my_rank] = nid;
             st_new += n_new;
             CPH_TICK(3);
 
@@ -979,7 +1012,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     const uint32_t pos = beam_size + __builtin_amdgcn_mbcnt_lo(pm, 0u);
                     const bool in_lds = beam_size + np <= kBeamLds;   // wave-uniform: the usual case keeps its ds_* accesses
                     bool stay = true;
-                    if (p && pos > 0) stay = !((in_lds ? heap.lds_key((pos - 1) >> 1) : heap.raw_key((pos - 1) >> 1)) > est);
+                    if (in_lds) {
+                        // every lane reads a parent (lanes without a push: the root) and is masked afterwards
+                        const bool chk = p && pos > 0;
+                        stay = !(heap.lds_key(chk ? (pos - 1) >> 1 : 0u) > est) || !chk;
+                    } else if (p && pos > 0) {
+                        stay = !(heap.raw_key((pos - 1) >> 1) > est);
+                    }
                     if (__all(stay)) {
 #ifdef CPH_TRAFFIC_STATS
                         if (!in_lds) trf[3]++;

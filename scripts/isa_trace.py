@@ -18,14 +18,28 @@ def main():
     dec = json.load(open(sys.argv[3])) if len(sys.argv) > 3 and not sys.argv[3].startswith("-") else {}
     verbose = "-v" in sys.argv
     labels = {}
+    local = collections.defaultdict(list)          # inline-asm local labels "1:" -> line numbers
     for i, l in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
             labels[m.group(1)] = i
+        m = re.match(r"^\s*(\d+):\s*(;.*)?$", l)
+        if m:
+            local[m.group(1)].append(i)
+
+    def resolve(tgt, at):
+        m = re.match(r"^(\d+)([bf])$", tgt)
+        if not m:
+            return labels[tgt], tgt
+        cands = local[m.group(1)]
+        if m.group(2) == "b":
+            return max(c for c in cands if c <= at), None
+        return min(c for c in cands if c > at), None
     pc = labels[start]
     cur = start
     nbr = 0
     counts = collections.Counter()
+    seen_ann = collections.Counter()
     visited = []
     steps = 0
     while steps < 20000:
@@ -40,13 +54,13 @@ def main():
                 break
             visited.append(cur)
             continue
-        if not l or l.startswith((";", ".", "//")):
+        if not l or l.startswith((";", ".", "//")) or re.match(r"^\d+:\s*(;.*)?$", l):
             continue
         parts = l.split(None, 1)
         op = parts[0]
         if not re.match(r"^[a-z]", op):
             continue
-        operands = parts[1].split(";")[0] if len(parts) > 1 else ""
+        operands = parts[1].split(";")[0].strip() if len(parts) > 1 else ""
         counts[classify(op, operands)] += 1
         if verbose:
             print(f"{cur:14s} {l}")
@@ -58,14 +72,24 @@ def main():
         elif op.startswith("s_cbranch"):
             key = f"{cur}#{nbr}"
             nbr += 1
-            taken = dec.get(key, False)
+            ann = l.split(";")[-1].strip() if ";" in l else ""
+            seen_ann[ann] += 1
+            akey = f"{ann}#{seen_ann[ann]}"          # k-th branch attributed to that source line along this path
+            taken = dec.get(key, dec.get(akey, dec.get(ann, False)))
+            if key not in dec and (akey in dec or ann in dec):
+                key = akey if akey in dec else ann
             if verbose or key not in dec:
-                print(f"    [{key}] {l}   -> {'TAKEN' if taken else 'not taken'}{'' if key in dec else '   (default)'}")
+                ctx = [x.strip() for x in lines[max(0, pc - 3):pc] if x.strip() and not x.strip().endswith(":")]
+                for x in ctx:
+                    print("          " + x)
+                print(f"    [{key}] [{akey}] {l}   -> {'TAKEN' if taken else 'not taken'}{'' if key in dec else '   (default)'}")
             if taken:
                 tgt = operands.strip()
                 if tgt == start:
                     break
-                cur = tgt; pc = labels[tgt]; nbr = 0; visited.append(cur)
+                pc, name = resolve(tgt, pc)
+                if name:
+                    cur = name; nbr = 0; visited.append(cur)
         elif op == "s_endpgm":
             break
     print("blocks:", " ".join(visited))
