@@ -20,11 +20,16 @@ Other configs (parity-backed lines for profiles/, not the driver's default):
   c4     Deep10M-class 10M x 96 (D=128), 4-bit
   c5     streaming FastScan over the largest D=1024 / 2-bit block set that fits this GPU
   recall Gaussian 100k x 128, 2-bit, k=20: a workload where the reference algorithm meets recall@10 >= 0.95
+  recall1m the same at SIFT1M scale (1M x 128): the gate leg of the default line
 
 The JSON line also carries
   * qps_at_recall_gate (c2, N = 1): the metric's gate, recall@10 >= 0.95, is not reachable for the reference algorithm
-    on the SIFT-like data (our ids are the reference's bit for bit), so a short child run of the `recall` config --
-    where it is -- is condensed into this object: QPS, recall, kernel fraction of HBM peak,
+    on the SIFT-like data (our ids are the reference's bit for bit), so a short child run of the `recall1m` config --
+    Gaussian data at the same scale, 1M x 128, 2-bit, k = 20, where it is -- is condensed into this object: QPS, recall,
+    kernel fraction of HBM peak, the reference's QPS and the bit-level parity check on a bounded query sample,
+  * legs (c2, N = 1): condensed child lines of the BASELINE configs C3 (1M x 960) and C5 (streaming FastScan over the
+    largest block set that fits), each with its parity check; `legs_failed` lists legs that broke (exit code 3 under
+    CPH_BENCH_STRICT=1),
   * fastscan_stream: the streaming FastScan kernel on synthetic neighbour blocks of the config's
     shape (metric part 2: distances/s vs the HBM roofline),
   * roofline: the dominant kernel of the timed region (the persistent search kernel): algorithmic
@@ -32,8 +37,8 @@ The JSON line also carries
     (HIP events on the launch stream inside the library, steps serialised for this measurement),
     `traffic` from the PMC summary file of the same tree when one is committed, else null,
   * cpu_baseline: the compiled reference (oracle/_ref) or the scalar port (oracle/) on this box' host
-    cores, on a bounded sample of the same workload, with a bit-level parity check of its results
-    against the GPU's.
+    cores -- CPU model, cores and OpenMP binding stated, 16 bound threads by default -- on a bounded sample of the
+    same workload, with a bit-level parity check of its results against the GPU's; FastScan at N threads and at 1.
 """
 import argparse
 import hashlib
@@ -223,11 +228,16 @@ def set_omp_threads(n):
 
 def cpu_baseline(args, cfg, path, Q, stream, K, gpu_index=None):
     """Reference (or port) on the host cores: bounded sample of the same workload.  Thread count and binding are
-    stated and fixed (OMP_PROC_BIND / OMP_PLACES are set at the top of main(), before libgomp is loaded): the default
-    is the box' CPU share for one GPU (16 threads, one per core), not every logical CPU of a host that eight GPU
-    boxes share -- 256 oversubscribed threads were what made round 2's baseline swing 13-21 k QPS box to box."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import Oracle, RefHooks, ref_available, ref_module
+    stated and fixed (OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES are set here, before the checker libraries bring in
+    the system's libgomp): the default is the box' CPU share for one GPU (its cgroup quota: 16 CPUs -> 16 threads, one per
+    core), not every logical CPU of a host that eight GPU boxes share -- 256 oversubscribed threads were what made round
+    2's baseline swing 13-21 k QPS box to box."""
+    # The reference's OpenMP runtime (the system libgomp, loaded with the checker libraries below -- torch brings a
+    # private copy that is not involved) reads its environment when it is loaded: one thread per core, bound.  A bound
+    # runtime pins the calling thread to its first place, and child processes inherit that mask, so the process-wide
+    # mask is restored when the baseline is done (and first, in case something bound this thread already).
+    if AFFINITY0:
+        os.sched_setaffinity(0, AFFINITY0)
     info = host_cpu_info()
     avail = info["logical_cpus"]
     if info["physical_cores"]:
@@ -235,6 +245,19 @@ def cpu_baseline(args, cfg, path, Q, stream, K, gpu_index=None):
     if info["cgroup_cpu_quota"]:
         avail = max(1, min(avail, int(info["cgroup_cpu_quota"])))
     cores = max(1, min(avail, args.cpu_threads))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle, RefHooks, ref_available, ref_module
+    try:
+        return _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle, RefHooks, ref_available, ref_module)
+    finally:
+        if AFFINITY0:
+            os.sched_setaffinity(0, AFFINITY0)
+
+
+def _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle, RefHooks, ref_available, ref_module):
     out = {"cores": cores, "cpu": info,
            "omp": {"OMP_NUM_THREADS": cores, "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
                    "OMP_PLACES": os.environ.get("OMP_PLACES")}}
@@ -312,11 +335,11 @@ def cpu_baseline(args, cfg, path, Q, stream, K, gpu_index=None):
 
 
 def pmc_traffic_ratio(config, k):
-    """HBM bytes over algorithmic bytes of the search kernel, from the PMC summary committed for this
-    tree (profiles/r2_pmc_search.json, written by scripts/pmc_search.sh + scripts/pmc_summary.py from
-    separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 FETCH_SIZE correction).  None when the
-    file does not cover this workload."""
-    p = os.path.join(ROOT, "profiles", "r2_pmc_search.json")
+    """HBM bytes over algorithmic bytes of the search kernel, from the PMC summary committed for this tree
+    (profiles/r3_pmc_search.json, written by scripts/pmc_search.sh + scripts/pmc_summary.py from separate FETCH_SIZE /
+    WRITE_SIZE passes; FETCH_SIZE counts one 64-byte unit per 128-byte line request on gfx950 -- scripts/micro/
+    fetch_calib.hip -- hence the x2).  None when the file does not cover this workload."""
+    p = os.path.join(ROOT, "profiles", "r3_pmc_search.json")
     try:
         rec = json.load(open(p))
     except Exception:
@@ -327,6 +350,7 @@ def pmc_traffic_ratio(config, k):
 
 
 STEP_TIMES = os.environ.get("CPH_BENCH_STEP_TIMES") == "1"
+AFFINITY0 = None
 
 
 def child_line(args, extra, timeout):
@@ -392,7 +416,7 @@ def make_step(search_device, q_shard, k, packs, streams, use_dist, stream_ctx):
     buffer; with N > 1 the step ends with the result all-gather on the same stream (the reference returns the whole
     batch, src/bindings.cpp:199-211).  Steps alternate between two streams / scratch sets unless `serial`."""
     def step(i, serial):
-        j = 0 if serial else (i & 1)
+        j = 0 if serial else (i % len(streams))
         st = streams[j]
         ids, d = search_device(q_shard, k, out=(packs[j].ids, packs[j].dist), stream=st)
         if use_dist:
@@ -405,7 +429,7 @@ def make_step(search_device, q_shard, k, packs, streams, use_dist, stream_ctx):
 def timed_region(step, steps, warmup, serial, use_dist, dist, sync, dev, marks_log=None):
     """The contract's timed region: two untimed priming passes (allocator pools, RCCL's per-stream state), W warm-up
     steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier, MAX of the elapsed time over ranks."""
-    for i in range(2):
+    for i in range(4):
         step(i, serial)
     sync()
     for i in range(warmup):
@@ -521,12 +545,14 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="0 = the config's k")
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--serial", action="store_true", help="one stream: every step waits for the previous one")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("CPH_BENCH_STREAMS", 4)),
+                    help="HIP streams / batch scratch sets the steps rotate over (batches in flight together)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("CPH_BENCH_SLOTS", 0)), help="resident query slots per batch (0 = automatic)")
     ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
     args = ap.parse_args()
 
-    # the CPU baseline's OpenMP runtime: one thread per core, bound (set before anything loads libgomp)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    global AFFINITY0
+    AFFINITY0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None   # before any OpenMP runtime binds this thread
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver (already exported on the boxes)
     import torch
     import torch.distributed as dist
@@ -594,9 +620,13 @@ def main():
         log(f"[bench] recall@10: {recall} (k={k_run})")
     del X
 
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    n_streams = max(1, min(4, args.streams))
+    index.set_batch_sets(n_streams)
+    if args.slots:
+        index.set_search_params(slots=args.slots, beam_capacity=0)
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     # ids and distances of a step share one byte buffer, so the N > 1 gather is one collective per step
-    packs = [PackedResults(nq_gpu, k_run, world, dev) for _ in range(2)]
+    packs = [PackedResults(nq_gpu, k_run, world, dev) for _ in range(n_streams)]
     outs = [(p.ids, p.dist) for p in packs]
     step = make_step(index.search_batch_device, q_shard, k_run, packs, streams, use_dist, torch.cuda.stream)
 
@@ -613,6 +643,9 @@ def main():
     # ---- the search kernel alone (steps serialised on one stream, HIP events inside the library) ----
     kernel_us = []
     stats = None
+    index.set_batch_sets(2)                                   # the kernel alone: every resident slot for one batch
+    if args.slots:
+        index.set_search_params(slots=0, beam_capacity=0)
     for i in range(args.warmup + args.steps):
         index.search_batch_device(q_shard, k_run, out=outs[0], stream=streams[0])
         if i >= args.warmup:
@@ -667,8 +700,10 @@ def main():
                        "nq_per_gpu": nq_gpu, "index_builder": build_info["builder"],
                        "index_build_s": build_info["build_s"],
                        "step": ("one stream, each step waits for the previous one" if args.serial else
-                                "steps alternate between two HIP streams (two batch scratch sets): a step starts "
-                                "while the previous one drains") + ("; ends with the RCCL all-gather" if use_dist else ""),
+                                f"steps rotate over {n_streams} HIP streams (as many batch scratch sets" +
+                                (", half of the resident slots per batch: two batches run side by side, the next ones "
+                                 "fill their drain)" if n_streams > 2 else "): a step starts while the previous one drains")) +
+                               ("; ends with the RCCL all-gather" if use_dist else ""),
                        "parallelism": f"query-sharded x{world}, index replicated"},
             "recall_at_10": recall,
             "recall_target_met": gate,
@@ -712,10 +747,11 @@ def main():
                 out["legs"] = {"error": repr(e)[:500]}
                 failed.append("legs")
         out["timed_region_s"] = elapsed
+        out["legs_failed"] = failed          # loud in the line itself; CPH_BENCH_STRICT=1 also turns it into exit code 3
         print(json.dumps(out), flush=True)
         if failed:
             log(f"[bench] FAILED legs: {failed}")
-            leg_failure = True
+            leg_failure = os.environ.get("CPH_BENCH_STRICT") == "1"
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -144,6 +144,11 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
  * matching these rows against its own base vectors. */
 int cph_get_vectors(cph_index* h, uint64_t first, uint64_t count, float* out);
 
+/* Batch scratch sets in rotation (default 2, at most 4): that many batches enqueued on different streams can be in
+ * flight together, each on its own slots -- with fewer slots per batch (cph_set_search_params) the drain of one batch
+ * is filled by the others.  Waits for everything enqueued on the handle. */
+int cph_set_batch_sets(cph_index* h, uint32_t n_sets);
+
 /* Tuning knobs (0 = automatic): resident query slots and per-slot beam capacity. */
 int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
 

@@ -36,6 +36,7 @@ SYMBOLS = {
     "cph_search_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
     "cph_synchronize": (C.c_int, [C.c_void_p]),
+    "cph_set_batch_sets": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cph_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                              C.POINTER(C.c_uint64)]),
     "cph_get_vectors": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -158,6 +158,10 @@ class CPIndex:
         return bool(f.value)
 
     # -- extras (not in the reference) ------------------------------------------------------
+    def set_batch_sets(self, n_sets):
+        """Batch scratch sets in rotation (1..4, default 2): batches that can be in flight together on different streams."""
+        _lib.check(_lib.lib().cph_set_batch_sets(self._h, int(n_sets)))
+
     def set_search_params(self, slots=0, beam_capacity=0):
         _lib.check(_lib.lib().cph_set_search_params(self._h, int(slots), int(beam_capacity)))
 

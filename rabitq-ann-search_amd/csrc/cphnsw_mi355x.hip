@@ -115,6 +115,7 @@ struct BatchSet {
     uint32_t run_slots = 0;   // slots its search launch used
 };
 constexpr int kStatWords = 18;
+constexpr int kMaxBatchSets = 4;
 constexpr uint64_t kSmallBatch = 32;        // batches up to this size take the copy-free path of cph_search / cph_search_batch
 
 struct cph_index {
@@ -147,8 +148,9 @@ struct cph_index {
     NativeMapping native_map;
     const uint8_t* own_view = nullptr;
     std::vector<uint8_t> own_store;    // own-code headers of an index built here (own_view points into it)
-    BatchSet sets[2];
-    int last_set = 1;                  // the set handed out last (the two alternate)
+    BatchSet sets[kMaxBatchSets];
+    int n_sets = 2;                    // sets in rotation (cph_set_batch_sets): batches that may be in flight together
+    int last_set = kMaxBatchSets - 1;  // the set handed out last (they take turns)
     int last_search = -1;              // the set the most recent search went to
     hipStream_t own_stream = nullptr;  // host-API calls (cph_search_batch, cph_search, hooks)
     bool order_queries = true;         // CPH_QUERY_ORDER=0 disables the closest-entry-first launch order
@@ -303,7 +305,7 @@ void materialize_search_data(cph_index* h) {
 // Picks the set for the next batch (the two alternate) and makes `st` wait for the batch that
 // used it before.  If that batch had to re-run queries, later batches get a larger capacity.
 BatchSet& next_set(cph_index* h, hipStream_t st) {
-    h->last_set ^= 1;
+    h->last_set = (h->last_set + 1) % h->n_sets;
     BatchSet& s = h->sets[h->last_set];
     if (!s.ev0) {
         HIP_CHECK(hipEventCreate(&s.ev0));
@@ -473,7 +475,12 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         const size_t lds_wave = search_lds_bytes(h->L.D, h->L.PW, k);
         wpc = (uint32_t)std::max<size_t>(1, std::min<size_t>(wpc, (160u * 1024u) / lds_wave));
     }
-    const uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc;
+    uint32_t max_slots = h->want_slots ? h->want_slots : (uint32_t)h->num_cus * wpc;
+    // More than two sets in rotation: a batch gets exactly half of the resident slots, so that two batches run side by
+    // side at full occupancy while the others queue behind them -- the drain of one is filled by the start of the
+    // next-but-one (C2, 10k-query batches on four streams: 5.34 -> 5.61 M QPS; 2,560 / 3,584 / 4,096 slots per batch or
+    // three sets all lose against two sets with every slot, profiles/r3_streams_sweep.md)
+    if (!h->want_slots && h->n_sets > 2) max_slots = std::max<uint32_t>(64, max_slots / 2);
     // balanced rounds: every slot runs the same number of queries (10k queries on 4096 slots
     // would leave 56% of the slots idle during the third round)
     const uint32_t rounds = (nq + max_slots - 1) / max_slots;
@@ -515,7 +522,7 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     }
     uint32_t* d_count = d_count_out ? d_count_out : s.d_count.p;
     HIP_CHECK(hipEventRecord(s.ev0, st));
-    if (s.cap < n + 1 && nq <= s.r_slots) {
+    if (s.cap < n + 1 && nq <= s.r_slots && !h->want_cap && !h->want_slots) {   // (explicit search params keep the general path)
         // a handful of queries: straight onto the full-capacity slots -- one launch, nothing can overflow
         s.run_slots = nq;
         launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 2, st);
@@ -976,6 +983,19 @@ int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity) 
         std::lock_guard<std::mutex> lk(h->mu);
         h->want_slots = slots;
         h->want_cap = beam_capacity;
+    });
+}
+
+int cph_set_batch_sets(cph_index* h, uint32_t n_sets) {
+    return guarded([&] {
+        if (!h) throw InvalidArg("null handle");
+        if (n_sets < 1 || n_sets > (uint32_t)kMaxBatchSets) throw InvalidArg("n_sets must be 1.." + std::to_string(kMaxBatchSets));
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->use_device();
+        quiesce(h);
+        for (int i = (int)n_sets; i < kMaxBatchSets; ++i) release_scratch(h->sets[i]);
+        h->n_sets = (int)n_sets;
+        h->last_set = (int)n_sets - 1;
     });
 }
 

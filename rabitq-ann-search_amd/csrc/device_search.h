@@ -329,7 +329,7 @@ __device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lan
         }
         d = 31u - (uint32_t)__builtin_clz(hp);
     }
-    if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
+    if (2 * hp == len) {                           // a last node with a left child only: len even, hole == (len - 2) / 2
         hp = 2 * hp;
         ++d;
     }
@@ -455,7 +455,7 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
         if (lane < 62 && idx < len) key = __uint_as_float(h.gt[beam_tail_off(idx)]);
         steps = walk(key, idx);
     }
-    if ((len & 1) == 0 && hp - 1 == (len - 2) >> 1) {   // a last node with a left child only
+    if (2 * hp == len) {                           // a last node with a left child only: len even, hole == (len - 2) / 2
         hp = 2 * hp;
         ++d;
     }
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
         uint32_t beam_size = 0, nn_size = 0;
         float gamma_q = gamma;
         // gamma-adaptation running sums live in LDS (touched only when a neighbour is reranked)
-        if (lane == 0) { s_ratio[0] = 0.0; s_ratio[1] = 0.0; }
+        if (lane == 0) { s_ratio[0] = 0.0; s_ratio[1] = 0.0; nn[0].dist = FMAX; }   // (an empty result heap reads as threshold FLT_MAX)
         uint32_t ratio_count = 0;
         // uniform state
         uint32_t log_count = 0;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             };
             {
                 const uint4 topv = heap.lds(0);
-                const float worst = nn_size ? nn[0].dist : FMAX;
+                const float worst = nn[0].dist;       // FLT_MAX while the result heap is empty (set at query start)
                 cur_id = bcast_u32(topv.z);
                 const float cur_est = __uint_as_float(topv.x);
                 const float cur_lower = __uint_as_float(topv.y);
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             if (nn_changes) {
                 nn_push_wave(nnw, nn, nn_size, k, cur_id, exact_dist, worst_pop, lane);
                 __builtin_amdgcn_wave_barrier();
-                worst0 = bcast_f32(nn_size ? nnw.lds_key(0) : FMAX);
+                worst0 = bcast_f32(nnw.lds_key(0));   // (the heap holds at least the entry just pushed)
             }
             const uint32_t nn_sz = nn_size;
             CPH_TICK(1);
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     const uint32_t id_i = (uint32_t)__builtin_amdgcn_readlane((int)nid, i);
                     const float e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(est), i));
                     const float lo_i = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(lower), i));
-                    const float worst = bcast_f32(nn_size ? nnw.lds_key(0) : FMAX);
+                    const float worst = bcast_f32(nnw.lds_key(0));   // FLT_MAX while the heap is empty
                     const float dabs = (nn_size >= k) ? gamma_q * worst : FMAX;
                     // 1 = rerank (result-heap push), 4 = ... and feed the gamma adaptation, 2 = DABS enqueue on the estimate
                     uint32_t act = 0;

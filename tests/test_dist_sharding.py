@@ -145,7 +145,7 @@ def _bench_step_worker(rank, world, port, nq, k, q):
         t0 = time.perf_counter()
         el, ids, d = bench.timed_region(step, steps, warmup, False, True, dist, lambda: None, dev)
         wall = time.perf_counter() - t0
-        assert len(calls) == 2 + warmup + steps and calls[-2:] == ["s0", "s1"]       # steps alternate the two sets
+        assert len(calls) == 4 + warmup + steps and calls[-2:] == ["s0", "s1"]       # steps alternate the two sets
         # after the last step (i = 3 -> set 1) that set's gather buffer holds the whole batch, rank-major
         nqk = nq * k
         all_ids = packs[1].all[:, : nqk * 8].contiguous().view(torch.int64).view(world * nq, k)

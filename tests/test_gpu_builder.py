@@ -215,6 +215,18 @@ def test_graph_quality_at_benchmark_scale_tracks_the_reference(tmp_path):
         rec_r = dedup_recall(ids_r, rr, gt, X)
         print(f"100k clustered, 4-bit: dedup recall@10 of k={k}: ours {rec_m:.4f}, reference {rec_r:.4f}")
         assert rec_m >= rec_r - 0.03, (k, rec_m, rec_r)
+    # an index of this size (n + 1 beyond the default per-slot capacity) is where the copy-free small-batch path runs:
+    # a handful of queries go straight onto the full-capacity slots, read and written over PCIe by the kernels
+    ids_b, d_b = mine.search_batch(Q, 20)
+    ids5, d5 = mine.search_batch(Q[:5], 20)
+    assert np.array_equal(ids5, ids_b[:5]) and d5.tobytes() == d_b[:5].tobytes()
+    for qi in (7, 8, 299):
+        i1, d1 = mine.search(Q[qi], 20)
+        m = int((ids_b[qi] >= 0).sum())
+        assert np.array_equal(i1, ids_b[qi, :m]) and d1.tobytes() == d_b[qi, :m].tobytes()
+    ids32, d32 = mine.search_batch(Q[100:132], 100)
+    ids_k100, d_k100 = mine.search_batch(Q, 100)
+    assert np.array_equal(ids32, ids_k100[100:132]) and d32.tobytes() == d_k100[100:132].tobytes()
 
 
 def test_build_errors():
