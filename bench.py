@@ -245,22 +245,31 @@ def cpu_baseline(args, cfg, path, Q, stream, K, gpu_index=None):
     if info["cgroup_cpu_quota"]:
         avail = max(1, min(avail, int(info["cgroup_cpu_quota"])))
     cores = max(1, min(avail, args.cpu_threads))
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")}
     os.environ["OMP_NUM_THREADS"] = str(cores)
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
+    omp_env = {k: os.environ.get(k) for k in saved}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, RefHooks, ref_available, ref_module
     try:
-        return _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle, RefHooks, ref_available, ref_module)
+        out = _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle, RefHooks, ref_available, ref_module)
+        out["omp"] = omp_env
+        return out
     finally:
+        # neither the binding nor its environment may leak into the child legs (their torch / builder threads would all
+        # land on one core)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         if AFFINITY0:
             os.sched_setaffinity(0, AFFINITY0)
 
 
 def _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle, RefHooks, ref_available, ref_module):
-    out = {"cores": cores, "cpu": info,
-           "omp": {"OMP_NUM_THREADS": cores, "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
-                   "OMP_PLACES": os.environ.get("OMP_PLACES")}}
+    out = {"cores": cores, "cpu": info}
     dim, bits = cfg["dim"], cfg["bits"]
     D = 1 << (dim - 1).bit_length()
     sample_q = Q[: min(len(Q), args.cpu_queries)]

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
         // uniform state
         uint32_t log_count = 0;
         int slack_batch = 0;
-        bool overflow = false;
+        bool overflow = false, wipe = false;
         uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0, st_allseen = 0;
 #ifdef CPH_TRAFFIC_STATS
         // diagnostic build only: what the spilled beam and the estimated-set probe touch (stats[8..15])
@@ -918,10 +918,15 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // neighbour order) under ONE predicate; a log that would overflow ends the attempt before anything is marked
             const uint32_t n_new = __popc(new_mask);
             const uint32_t my_rank = __builtin_amdgcn_mbcnt_lo(new_mask, 0u);   // set bits below this lane (lanes < 32)
-            if (log_count + n_new > a.cap) { overflow = true; break; }
+            // The beam must have room for this expansion's pushes (at most one per new id); a query that outgrows its
+            // slot is answered by the full-capacity re-run.  The id log only exists to clear the bitmap cheaply: once it
+            // is full the query simply stops logging and wipes its whole bitmap at the end (n / 8 bytes -- less than the
+            // log it would have needed: a query that discovers more than `cap` ids has touched a good part of the graph).
+            if (beam_size + n_new > a.cap) { overflow = true; break; }
+            if (!wipe && log_count + n_new > a.cap) wipe = true;
             if (is_new) {
                 atomicOr(&bm[nid >> 5], my_bit);
-                logi[log_count + my_rank] = nid;
+                if (!wipe) logi[log_count + my_rank] = nid;
             }
             // slack level schedule (:141-145)
             if (a.sc.num_slack > 0) {
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
         }
         // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --
         __syncthreads();
-        if (overflow) {
+        if (overflow || wipe) {
             const uint64_t bm_words = CPH_COLD(bm_words);
             for (uint64_t w = lane; w < bm_words; w += 64) bm[w] = 0u;
         } else {
