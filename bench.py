@@ -435,10 +435,10 @@ def make_step(search_device, q_shard, k, packs, streams, use_dist, stream_ctx):
     return step
 
 
-def timed_region(step, steps, warmup, serial, use_dist, dist, sync, dev, marks_log=None):
+def timed_region(step, steps, warmup, serial, use_dist, dist, sync, dev, marks_log=None, prime=4):
     """The contract's timed region: two untimed priming passes (allocator pools, RCCL's per-stream state), W warm-up
     steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier, MAX of the elapsed time over ranks."""
-    for i in range(4):
+    for i in range(prime):
         step(i, serial)
     sync()
     for i in range(warmup):
@@ -554,8 +554,9 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="0 = the config's k")
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--serial", action="store_true", help="one stream: every step waits for the previous one")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("CPH_BENCH_STREAMS", 4)),
-                    help="HIP streams / batch scratch sets the steps rotate over (batches in flight together)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("CPH_BENCH_STREAMS", 0)),
+                    help="HIP streams / batch scratch sets the steps rotate over (batches in flight together); 0 = a short "
+                         "untimed trial of 2 and 4 picks the faster")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("CPH_BENCH_SLOTS", 0)), help="resident query slots per batch (0 = automatic)")
     ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
     args = ap.parse_args()
@@ -629,15 +630,34 @@ def main():
         log(f"[bench] recall@10: {recall} (k={k_run})")
     del X
 
-    n_streams = max(1, min(4, args.streams))
-    index.set_batch_sets(n_streams)
-    if args.slots:
-        index.set_search_params(slots=args.slots, beam_capacity=0)
-    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    all_streams = [torch.cuda.Stream(dev) for _ in range(4)]
     # ids and distances of a step share one byte buffer, so the N > 1 gather is one collective per step
-    packs = [PackedResults(nq_gpu, k_run, world, dev) for _ in range(n_streams)]
+    all_packs = [PackedResults(nq_gpu, k_run, world, dev) for _ in range(4)]
+
+    def configure(ns):
+        index.set_batch_sets(ns)
+        index.set_search_params(slots=args.slots, beam_capacity=0)
+        return make_step(index.search_batch_device, q_shard, k_run, all_packs[:ns], all_streams[:ns], use_dist, torch.cuda.stream)
+
+    tuning = None
+    if args.streams > 0:
+        n_streams = max(1, min(4, args.streams))
+    else:
+        # Batches in flight: two sets with every slot, or four sets with half of the slots each (cph_set_batch_sets).
+        # Which one packs the machine better depends on the length of the queries (C2: four, +5 %; C4: two, +9 %), so
+        # it is settled by a short untimed trial before the warm-up -- what a serving process would do once at start-up.
+        # Every rank takes the same decision (MAX over ranks of the trial times).
+        tuning = {}
+        for ns in (2, 4):
+            trial_steps = max(2, min(8, args.steps))
+            el, _, _ = timed_region(configure(ns), trial_steps, 0, False, use_dist, dist, torch.cuda.synchronize, dev, prime=ns)
+            tuning[ns] = el / trial_steps
+        n_streams = min(tuning, key=tuning.get)
+        log(f"[bench] rank {rank}: batches in flight: trial " + ", ".join(f"{ns} sets {1e3 * t:.3f} ms/step" for ns, t in tuning.items())
+            + f" -> {n_streams}")
+    step = configure(n_streams)
+    streams, packs = all_streams[:n_streams], all_packs[:n_streams]
     outs = [(p.ids, p.dist) for p in packs]
-    step = make_step(index.search_batch_device, q_shard, k_run, packs, streams, use_dist, torch.cuda.stream)
 
     def timed(steps, serial):
         return timed_region(step, steps, args.warmup, serial, use_dist, dist, torch.cuda.synchronize, dev,
@@ -713,6 +733,8 @@ def main():
                                 (", half of the resident slots per batch: two batches run side by side, the next ones "
                                  "fill their drain)" if n_streams > 2 else "): a step starts while the previous one drains")) +
                                ("; ends with the RCCL all-gather" if use_dist else ""),
+                       "batch_sets": n_streams,
+                       "batch_sets_trial_ms_per_step": ({str(ns): round(1e3 * t, 4) for ns, t in tuning.items()} if tuning else None),
                        "parallelism": f"query-sharded x{world}, index replicated"},
             "recall_at_10": recall,
             "recall_target_met": gate,

@@ -900,6 +900,45 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 continue;
             }
 
+            // slack level schedule (:141-145)
+            if (a.sc.num_slack > 0) {
+                int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
+                qp.slack = s_slack[lvl];
+                ++slack_batch;
+            }
+            // ---- FastScan estimates (:159-206) ----------------------------------------
+            float est = 0.0f, lower = 0.0f;
+            bool skipped2 = false;
+            auto estimate = [&]() {
+                LaneEst v;
+                bl.reduce(blk, a.L, qm, lane, v);
+                const float dqp = exact_dist;
+                const float sq = __builtin_sqrtf(dqp);
+                if constexpr (BW == 1) {
+                    stage2_est<1>(qp, v, dqp, sq, est, lower);
+                } else {
+                    // both lower bounds at once, one per lane half (see lower_bounds_split); dqp is the popped vertex's
+                    // distance, the same in every lane
+                    float lo1 = 0.0f, lo2 = 0.0f;
+                    if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2);
+                    bool surv = (nn_sz < k) || (valid && lo1 < worst0);
+                    if (__any(surv)) {
+                        est = stage2_est_only<BW>(qp, v, dqp);
+                        lower = lo2;
+                    } else {
+                        est = FMAX;
+                        lower = lo1;
+                        skipped2 = true;
+                    }
+                }
+            };
+            // Narrow codes (1- and 2-bit) estimate poorly, so their searches run long, almost always find something new
+            // (9 % of the gate workload's expansions are all-seen, 24 % of C2's) and are bound by dependent round trips,
+            // not by bandwidth: there the estimator runs BEFORE the probe's result is looked at, under its round trip.
+            // The 4-bit kernel keeps the order that skips the arithmetic of all-seen expansions.
+            constexpr bool kSpeculate = BW <= 2;
+            if constexpr (kSpeculate) estimate();
+
             // ---- estimated set: result of the probe issued above --------------------------------
             bool is_new = active && (old_bits & my_bit) == 0;
             // a vertex whose neighbour list repeats an id: only the first copy is new
@@ -928,12 +967,6 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 atomicOr(&bm[nid >> 5], my_bit);
                 if (!wipe) logi[log_count + my_rank] = nid;
             }
-            // slack level schedule (:141-145)
-            if (a.sc.num_slack > 0) {
-                int lvl = slack_batch < a.sc.num_slack - 1 ? slack_batch : a.sc.num_slack - 1;
-                qp.slack = s_slack[lvl];
-                ++slack_batch;
-            }
             // Every neighbour already estimated (a quarter to a third of the expansions, most of
             // them late in the search): the reference evaluates the block and then skips all 32
             // neighbours (:227), so nothing it computes is observable -- the FastScan arithmetic,
@@ -942,30 +975,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 ++st_allseen;
                 continue;
             }
-            LaneEst v;
-            bl.reduce(blk, a.L, qm, lane, v);
-            const float dqp = exact_dist;
-            const float sq = __builtin_sqrtf(dqp);
-
-            // ---- FastScan estimates (:159-206) ----------------------------------------
-            float est, lower;
-            if constexpr (BW == 1) {
-                stage2_est<1>(qp, v, dqp, sq, est, lower);
-            } else {
-                // both lower bounds at once, one per lane half (see lower_bounds_split); dqp is the popped vertex's
-                // distance, the same in every lane
-                float lo1 = 0.0f, lo2 = 0.0f;
-                if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2);
-                bool surv = (nn_sz < k) || (valid && lo1 < worst0);
-                if (__any(surv)) {
-                    est = stage2_est_only<BW>(qp, v, dqp);
-                    lower = lo2;
-                } else {
-                    est = FMAX;
-                    lower = lo1;
-                    st_skip++;
-                }
-            }
+            if constexpr (!kSpeculate) estimate();
+            if (skipped2) st_skip++;
 
             CPH_TICK(2);
             const bool warmup = nn_sz < k;  // (:210)
