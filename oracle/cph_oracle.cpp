@@ -709,6 +709,10 @@ extern "C" int orc_std_heap_ops(const uint8_t* ops, uint64_t n_ops, const float*
     size_t next = 0;
     auto comp = [](const BeamEntry& a, const BeamEntry& b) { return a.est > b.est; };
     for (uint64_t j = 0; j < n_ops; ++j) {
+        if (ops[j] == 2 && !h.empty()) {        // 2 = pop, then push (one expansion's heap traffic)
+            std::pop_heap(h.begin(), h.end(), comp);
+            h.pop_back();
+        }
         if (ops[j]) {
             h.push_back(BeamEntry{keys[next], 0.0f, ids[next]});
             ++next;

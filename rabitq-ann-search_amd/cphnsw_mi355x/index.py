@@ -306,12 +306,13 @@ def select_neighbors_debug(x, vertex, fwd, rev, R, alpha, tau, alpha_max=0.0, er
 
 
 def heap_ops_debug(ops, keys, ids, device=None):
-    """Self-test hook: runs a push (1) / pop (0) sequence through the beam's wave-parallel heap routines (first 255
-    entries in LDS, the rest in HBM) and returns the heap array (keys f32, ids u32)."""
+    """Self-test hook: runs a push (1) / pop (0) / pop-then-push (2: the way one expansion does it, with the leaf's
+    ancestors fetched ahead of the pop) sequence through the beam's wave-parallel heap routines (first 255 entries in
+    LDS, the rest in HBM) and returns the heap array (keys f32, ids u32)."""
     ops = np.ascontiguousarray(ops, np.uint8)
     keys = np.ascontiguousarray(keys, np.float32)
     ids = np.ascontiguousarray(ids, np.uint32)
-    n_push = int(ops.sum())
+    n_push = int((ops != 0).sum())
     assert len(keys) == n_push and len(ids) == n_push
     ok = np.zeros(max(1, n_push), np.float32)
     oi = np.zeros(max(1, n_push), np.uint32)

@@ -1015,7 +1015,10 @@ int cph_last_search_stats(cph_index* h, uint64_t out[12]) {
         out[7] = s.pin_stats[7];
         out[8] = s.run_slots;
         out[9] = s.cap;
-#ifdef CPH_PHASE_TIMERS
+#if CPH_PHASE_TIMERS + 0 == 2
+        fprintf(stderr, "[fine cycles] head+issue=%llu pop=%llu block_wait=%llu probe_issue+exact+nnpush=%llu estimator=%llu probe_wait=%llu mark+cand=%llu pushes+tail=%llu\n",
+                s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);
+#elif defined(CPH_PHASE_TIMERS)
         fprintf(stderr, "[phase cycles] pop=%llu load+exact+nnpush=%llu sums+epi=%llu atomic+log+stage=%llu spec_exact=%llu replay=%llu tail=%llu other=%llu\n",
                 s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);
 #endif

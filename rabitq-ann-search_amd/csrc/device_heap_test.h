@@ -12,7 +12,8 @@
 namespace cph {
 
 struct HeapTestArgs {
-    const uint8_t* ops;      // [n_ops] 1 = push the next (key, id), 0 = pop
+    const uint8_t* ops;      // [n_ops] 1 = push the next (key, id), 0 = pop, 2 = pop, then push the next (key, id): what one
+                             // expansion of the search does to its beam
     const float* keys;       // [pushes]
     const uint32_t* ids;     // [pushes]
     uint32_t n_ops;
@@ -32,6 +33,14 @@ __global__ __launch_bounds__(64) void heap_selftest_kernel(HeapTestArgs a) {
     heap.gt = a.tail;
     uint32_t size = 0, next = 0;
     for (uint32_t j = 0; j < a.n_ops; ++j) {
+        if (a.ops[j] == 2 && size > 0) {
+            if (size > 1) {
+                if (size <= kBeamLds) heap_pop_wave(heap, size, lane);
+                else beam_pop_hybrid(heap, size, lane);
+            }
+            --size;
+            __builtin_amdgcn_wave_barrier();
+        }
         if (a.ops[j]) {
             const uint4 v = make_uint4(__float_as_uint(a.keys[next]), 0u, a.ids[next], 0u);
             ++next;

@@ -171,6 +171,17 @@ struct BeamEntry {
     uint32_t id;
 };
 
+// The lane id as a value the optimiser cannot see through.  Everything a routine derives from the lane id alone is
+// loop-invariant, so the compiler computes it once per kernel and keeps it in a VGPR across the whole expansion loop -- for
+// the spilled-beam routines that is a dozen registers the usual expansion never uses, i.e. spills, and a spill reload inside
+// the loop is a vector-memory operation in the middle of the round trips the loop overlaps (it waits for all of them:
+// scripts/loop_reloads.py counts them, the count has to stay at zero on the usual path).  Routines off the usual path
+// start from a laundered copy: two or three cheap instructions recomputed where they are used.
+__device__ __forceinline__ int opaque_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
 // The LDS part is addressed through address-space-3 pointers so that every access is a ds_*
 // instruction (a generic pointer would make them flat_* accesses, which also wait on vmcnt).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -382,7 +393,8 @@ __device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typena
 // heap-ordered tail and fetch those levels' path entries in a second round trip.
 // History: lane-0 sifts 334 ms per 10,000 queries of that workload; windows of keys over 16-byte entries in heap
 // order + a dependent read of the path (round 2) 216 ms; pages (round 3): see DESIGN.md section 6.
-__device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, int lane) {
+__device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, int lane_in) {
+    const int lane = opaque_lane(lane_in);
     const uint32_t len = size - 1;                 // >= kBeamLds: the last element lives in HBM
     const uint4 v = Beam::load3(h.spill_ptr(len));       // the value __adjust_heap re-inserts (same address in every lane)
     // LDS levels 0..6: nodes 0..126, both children always inside the LDS part
@@ -496,7 +508,8 @@ __device__ __forceinline__ void beam_pop_hybrid(const Beam& h, uint32_t size, in
 // std::push_heap of `v` at index `hole` >= kBeamLds: heap_push_wave on the hybrid accessors -- the ancestors of the
 // leaf (LDS or HBM, by index) are read by one lane each, one round trip whatever the depth.  A leaf inside the pages
 // (hole < 8191: the usual case) has all its HBM ancestors in its own page, at the leaf's relative index shifted right.
-__device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, uint4 v, int lane) {
+__device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, uint4 v, int lane_in) {
+    const int lane = opaque_lane(lane_in);
     const uint32_t hp = hole + 1;
     const uint32_t depth = 31u - (uint32_t)__builtin_clz(hp);
     const uint32_t t = (uint32_t)lane + 1;
@@ -536,7 +549,12 @@ __device__ __forceinline__ void beam_push_hybrid(const Beam& h, uint32_t hole, u
 // heap's current root key.  Same element movement as nn_push (which stays as the path for heaps too large for
 // the two ballot masks of the wave-parallel pop).
 __device__ __forceinline__ void nn_push_wave(const NnLds& w, Result* h, uint32_t& size, uint32_t k, uint32_t id, float dist,
-                                             float top, int lane) {
+                                             float top, int lane_in) {
+#ifndef CPH_NO_LAUNDER_NN
+    const int lane = opaque_lane(lane_in);     // (one expansion in four or fewer gets here: see opaque_lane)
+#else
+    const int lane = lane_in;
+#endif
     const uint2 r = make_uint2(id, __float_as_uint(dist));
     if (size < k) {
         if (size < kWaveHeapMax) {
@@ -719,9 +737,20 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
 #ifdef CPH_PHASE_TIMERS
         unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tlast = clock64();
-#define CPH_TICK(i) do { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
+#define CPH_TICK_(i) do { unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; } while (0)
+        // -DCPH_PHASE_TIMERS=2: finer buckets along one expansion's dependent chain (CPH_TICKF), for the latency-bound workloads:
+        // 0 head + load issue | 1 pop (incl. its windows) | 2 rest of the block wait | 3 probe issue, exact distance, result push |
+        // 4 estimator | 5 rest of the probe wait | 6 marking, candidates, speculative rerank | 7 beam pushes + loop tail
+#if CPH_PHASE_TIMERS + 0 == 2
+#define CPH_TICK(i) do {} while (0)
+#define CPH_TICKF(i) CPH_TICK_(i)
+#else
+#define CPH_TICK(i) CPH_TICK_(i)
+#define CPH_TICKF(i) do {} while (0)
+#endif
 #else
 #define CPH_TICK(i) do {} while (0)
+#define CPH_TICKF(i) do {} while (0)
 #endif
 
         // entry: ep_est = exact_l2(ep); beam.push({ep_est, 0, ep}); mark estimated (:95-97)
@@ -808,6 +837,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             BlockLoads<BW, SD> bl;
             bl.issue(blk, a.L, lane);
             __builtin_amdgcn_sched_barrier(0);
+            CPH_TICKF(0);
             // ---- the pop, while those loads are in flight.  It needs only the id of the top, which the loads
             // above already have; its three dependent LDS round trips and its scalar path walk (a fifth of an
             // expansion's time when it ran in front of the loads) now hide behind the block's memory latency.
@@ -834,6 +864,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             pop_beam(beam_size);
             --beam_size;
             __builtin_amdgcn_sched_barrier(0);
+            CPH_TICKF(1);
             // All of this expansion's loads come back together (issued back to back, retired in
             // order); they are retired HERE, before the probe goes out.  The probe is only issued when
             // a lane has something to look up, and a load that is only maybe in flight makes every
@@ -846,6 +877,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             if constexpr (SD < 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
             bl.retire();
             asm volatile("" : "+v"(cur_norm), "+v"(nid) : "v"(touch));
+            CPH_TICKF(2);
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
             const bool active = lane < 32 && valid;
             // The probe is a plain (device-coherent: it must not be served from this CU's L1, which
@@ -893,6 +925,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             }
             const uint32_t nn_sz = nn_size;
             CPH_TICK(1);
+            CPH_TICKF(3);
             if (!__any(active)) {  // n_neighbors == 0 (:137)
                 // (retire the probe's destination register on this path too: a load left pending
                 // across the back edge costs every expansion a wait where that register is reused)
@@ -938,6 +971,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // The 4-bit kernel keeps the order that skips the arithmetic of all-seen expansions.
             constexpr bool kSpeculate = BW <= 2;
             if constexpr (kSpeculate) estimate();
+            CPH_TICKF(4);
+#if CPH_PHASE_TIMERS + 0 == 2
+            asm volatile("" : "+v"(old_bits));
+            CPH_TICKF(5);
+#endif
 
             // ---- estimated set: result of the probe issued above --------------------------------
             bool is_new = active && (old_bits & my_bit) == 0;
@@ -1007,6 +1045,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 __syncthreads();
             }
             CPH_TICK(4);
+            CPH_TICKF(6);
 
             // ---- serial replay of the neighbour loop (:218-273).  The loop runs on lane 0 (heap
             // state lives there) but `i` comes from the wave-uniform ballot mask, so neighbour i's
@@ -1024,7 +1063,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 // are independent appends -- each lane checks its own parent and writes its own leaf.
                 const uint32_t np = __popc(pm);
                 bool appended = false;
+                // (a single push onto a spilled beam goes straight to the push routine: the parent check of the append path
+                // would be a dependent round trip of its own in front of the one the routine makes anyway)
+#ifdef CPH_NO_SKIP_APPEND
                 if (np != 0 && np <= beam_size + 1) {
+#else
+                if (np != 0 && np <= beam_size + 1 && !(np == 1 && beam_size >= kBeamLds)) {
+#endif
                     const uint32_t pos = beam_size + __builtin_amdgcn_mbcnt_lo(pm, 0u);
                     const bool in_lds = beam_size + np <= kBeamLds;   // wave-uniform: the usual case keeps its ds_* accesses
                     bool stay = true;
@@ -1131,6 +1176,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // compiler needs a fence here -- an s_barrier would also drain the prefetch (vmcnt)
             __builtin_amdgcn_wave_barrier();
             CPH_TICK(6);
+            CPH_TICKF(7);
         }
 
         // ---- results (:276; src/bindings.cpp:202-210) ----------------------------------

@@ -255,7 +255,7 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
-@pytest.mark.parametrize("n_fill", [1, 2, 3, 7, 254, 255, 256, 257, 300, 511, 512, 4095, 4096, 4097, 8191, 8192, 9000, 70000])
+@pytest.mark.parametrize("n_fill", [1, 2, 3, 7, 254, 255, 256, 257, 300, 511, 512, 4095, 4096, 4097, 8191, 8192, 9000, 16384, 70000, 262143, 262144, 270000])
 def test_beam_heap_routines_move_like_libstdcxx(cph, oracle, n_fill):
     """The beam's wave-parallel heap routines (heap_push_wave / heap_pop_wave in LDS, beam_push_hybrid / beam_pop_hybrid
     once it spills to HBM: windows of five levels) against libstdc++'s std::push_heap / std::pop_heap on the same
@@ -264,12 +264,14 @@ def test_beam_heap_routines_move_like_libstdcxx(cph, oracle, n_fill):
     everywhere.  The whole heap array must match after the last operation, element for element."""
     rng = np.random.default_rng(1000 + n_fill)
     for distinct in (8, 1 << 20):
-        mix = rng.integers(0, 2, size=600).astype(np.uint8)
+        # 0 = pop, 1 = push, 2 = pop-then-push the way one expansion does it (the leaf's ancestors fetched ahead of the pop
+        # into LDS, the push reading them from there unless the pop's path crossed them)
+        mix = rng.integers(0, 3, size=900).astype(np.uint8)
         drain = np.zeros(min(n_fill + 200, 700), np.uint8)
         refill = np.ones(300, np.uint8)
-        tail = rng.integers(0, 3, size=400).astype(np.uint8).clip(0, 1)      # pushes twice as likely as pops
+        tail = rng.choice(np.array([0, 1, 1, 2, 2, 2], np.uint8), size=600)
         ops = np.concatenate([np.ones(n_fill, np.uint8), mix, drain, refill, tail])
-        n_push = int(ops.sum())
+        n_push = int((ops != 0).sum())
         keys = rng.integers(0, distinct, size=n_push).astype(np.float32)
         ids = np.arange(n_push, dtype=np.uint32)
         gk, gi = cph.heap_ops_debug(ops, keys, ids)
