@@ -5,7 +5,7 @@ import re
 import sys
 
 txt = open(sys.argv[1]).read()
-for kn in re.findall(r"^(_ZN3cph13search_kernelILi\dELi\d+EEEvNS_10SearchArgsE):", txt, re.M):
+for kn in re.findall(r"^(_ZN3cph13search_kernelILi\dELi\d+E(?:Lb\dE)?EEvNS_10SearchArgsE):", txt, re.M):
     m = re.search(r"^%s:(.*?)^\s*\.end_amdhsa_kernel" % re.escape(kn), txt, re.S | re.M)
     lines = m.group(1).splitlines()
     cur, depth, out = None, 0, []

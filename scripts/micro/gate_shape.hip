@@ -32,14 +32,19 @@ __global__ __launch_bounds__(64) void shape_kernel(const unsigned char* __restri
         if (lane < 62) w0 = reinterpret_cast<const unsigned*>(pg + page * 768)[3 * lane];   // the window (12-byte entries)
         acc ^= c0.x ^ c1.y ^ r.w ^ w0;
         if (with_probe) {
-            // dependent trip: ids come out of the block
+            // dependent trip: ids come out of the block.  with_probe bits: 1 probe (device-coherent load), 2 marks as atomic OR,
+            // 4 marks as plain stores, 8 probe as a plain load instead, 16 the pushes' stores
             unsigned h = (c1.x ^ x ^ (lane * 2246822519u)) * 2654435761u;
             const unsigned word = (h >> 7) % bm_words;
             unsigned bits = 0;
-            if (lane < 32) bits = __hip_atomic_load(&bm[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 32) {
+                if (with_probe & 8) bits = bm[word];
+                else bits = __hip_atomic_load(&bm[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             acc ^= bits;
-            if (lane < 4) atomicOr(&bm[word], 1u << (h & 31));                                 // ~3.7 new ids per expansion
-            if (lane < 3) reinterpret_cast<unsigned*>(pg + page * 768)[3 * (lane + 5)] = acc;   // the pushes' stores
+            if ((with_probe & 2) && lane < 4) atomicOr(&bm[word], 1u << (h & 31));            // ~3.7 new ids per expansion
+            if ((with_probe & 4) && lane < 4) bm[word] = bits | (1u << (h & 31));
+            if ((with_probe & 16) && lane < 3) reinterpret_cast<unsigned*>(pg + page * 768)[3 * (lane + 5)] = acc;   // the pushes' stores
         }
         x ^= acc & 1u;
     }
@@ -57,8 +62,8 @@ int main(int argc, char** argv) {
     hipMemset(bm, 0, (size_t)max_grid * bm_words * 4); hipMemset(pg, 0, (size_t)max_grid * kPagesBytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 400;
-    for (int probe = 0; probe < 2; ++probe)
-        for (int wpc : {8, 16, 24, 32}) {
+    for (int probe : {0, 1, 1 | 2, 1 | 4, 1 | 8, 1 | 2 | 16, 1 | 4 | 16})
+        for (int wpc : {8, 24}) {
             if (wpc_only && wpc != wpc_only) continue;
             const int grid = 256 * wpc;
             for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(shape_kernel, dim3(grid), dim3(64), 0, 0, b, r, bm, pg, n, bm_words, iters, probe, o);
@@ -69,7 +74,9 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double exps = (double)grid * iters / (ms / reps) / 1e6;      // G expansions / s
             printf("n=%u %2d waves/CU, %s: %.3f ms -> %.3f G expansions/s, %.2f us per expansion and wave, %.0f GB/s algorithmic (2,180 B)\n", n, wpc,
-                   probe ? "block+row+page, then probe+marks+stores" : "block+row+page only", ms / reps, exps, grid / exps / 1e3, exps * 2180);
+                   probe == 0 ? "block+row+page only" : probe == 1 ? "... then probe (coherent load)" : probe == 3 ? "... probe, atomic marks" :
+                   probe == 5 ? "... probe, plain-store marks" : probe == 9 ? "... probe as a plain load" : probe == 19 ? "... probe, atomic marks, push stores" :
+                   "... probe, plain-store marks, push stores", ms / reps, exps, grid / exps / 1e3, exps * 2180);
         }
     return 0;
 }

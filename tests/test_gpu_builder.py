@@ -229,6 +229,31 @@ def test_graph_quality_at_benchmark_scale_tracks_the_reference(tmp_path):
     assert np.array_equal(ids32, ids_k100[100:132]) and d32.tobytes() == d_k100[100:132].tobytes()
 
 
+@pytest.mark.parametrize("bits", [1, 2, 4])
+def test_small_batch_path_equals_the_batch_path(bits):
+    """Batches of up to 32 queries on an index beyond the default slot capacity take the copy-free path: one launch on the
+    full-capacity slots, queries read and results written by the kernels over PCIe (cphnsw_mi355x.hip, launch mode 2).
+    Ids and distance bits must equal what the same queries get inside a large batch (the path the oracle and the
+    reference pin), for every code width and for `search`."""
+    import cphnsw_mi355x
+    rng = np.random.default_rng(40 + bits)
+    n, dim, nq = 70_000, 128, 200
+    X, cent = sift_like(rng, n, dim, 700)
+    Q = np.clip(np.round(cent[rng.integers(0, 700, nq)] + rng.normal(0, 12, (nq, dim))), 0, 218).astype(np.float32)
+    ix = cphnsw_mi355x.CPIndex(dim, bits)
+    ix.build(X)
+    ix.finalize()
+    for k in (10, 100):
+        ids_b, d_b = ix.search_batch(Q, k)
+        for lo, hi in ((0, 1), (1, 8), (8, 40)):
+            ids_s, d_s = ix.search_batch(Q[lo:hi], k)
+            assert np.array_equal(ids_s, ids_b[lo:hi]) and d_s.tobytes() == d_b[lo:hi].tobytes(), (bits, k, lo, hi)
+        for qi in (41, 42, 199):
+            i1, d1 = ix.search(Q[qi], k)
+            m = int((ids_b[qi] >= 0).sum())
+            assert np.array_equal(i1, ids_b[qi, :m]) and d1.tobytes() == d_b[qi, :m].tobytes(), (bits, k, qi)
+
+
 def test_build_errors():
     import cphnsw_mi355x
     ix = cphnsw_mi355x.CPIndex(128, 4)
