@@ -53,7 +53,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "rabitq-ann-search_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
-BUILDER_VERSION = "r2"         # part of the index cache key: bump when the builder changes
+BUILDER_VERSION = "r3"         # part of the index cache key: bump when the builder changes
 
 CONFIGS = {
     # name: generator, n, dim, bits, k, nq per GPU, stream blocks

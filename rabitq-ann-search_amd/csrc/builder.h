@@ -50,6 +50,7 @@
 #include "device_buf.h"
 #include "device_build.h"
 #include "device_knn.h"
+#include "device_knn_sym.h"
 #include "host_index.h"
 #include "host_parallel.h"
 #include "builder_host.h"
@@ -72,19 +73,94 @@ struct StageTimer {
 inline uint32_t grid_for(uint64_t items, uint32_t block) { return (uint32_t)((items + block - 1) / block); }
 
 // ---- exact kNN on the matrix cores (device pointers; D a multiple of 32) ----------------------------
+// exclude_self: query row i never lists column i -- or column q_ids[i] when the query rows are a gathered subset of the base
 inline void knn_device(const float* d_q, const float* d_qnorm, size_t nq, const float* d_b, const float* d_bnorm,
-                       size_t nb, size_t D, bool exclude_self, int num_cus, uint32_t* d_ids, float* d_dist) {
+                       size_t nb, size_t D, bool exclude_self, int num_cus, uint32_t* d_ids, float* d_dist,
+                       const uint32_t* d_q_ids = nullptr) {
     if (D % kKnnKC != 0 || nq == 0 || nb == 0) throw std::invalid_argument("knn_device: D must be a multiple of 32");
     // slices of row blocks, so that no single launch runs for minutes
     const uint32_t rows_per_launch = (uint32_t)num_cus * 8u * kKnnTile;
     for (size_t rb = 0; rb < nq; rb += rows_per_launch) {
         KnnArgs a{d_q, d_b, d_bnorm, d_qnorm, (uint32_t)nq, (uint32_t)nb, (uint32_t)D, (uint32_t)rb,
-                  (uint32_t)std::min<size_t>(nq, rb + rows_per_launch), exclude_self ? 1u : 0u, d_ids, d_dist};
+                  (uint32_t)std::min<size_t>(nq, rb + rows_per_launch), exclude_self ? 1u : 0u, d_ids, d_dist, d_q_ids};
         const uint32_t grid = (a.row_end - a.row_begin + kKnnTile - 1) / kKnnTile;
         hipLaunchKernelGGL(knn_mfma_kernel, dim3(grid), dim3(256), 0, nullptr, a);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
     }
+}
+
+// ---- the self-join: every tile of the distance matrix once (device_knn_sym.h) -----------------------------------------
+// d_x [n][D] against itself, a row never lists itself.  Small inputs, D = 32 (one chunk per tile: the staging protocol of
+// the column norms needs two) and CPH_KNN_SYM=0 take knn_mfma_kernel with every pair computed twice.
+inline bool knn_sym_wanted(size_t n, size_t D) {
+    static const int env = getenv("CPH_KNN_SYM") ? atoi(getenv("CPH_KNN_SYM")) : -1;
+    if (env == 0) return false;
+    const size_t min_n = env > 1 ? (size_t)env : 32768;      // CPH_KNN_SYM=<n>: lower the size limit (tests)
+    return n >= min_n && n / kKnnSymSample >= 64 && D >= 2 * kKnnKC && n < (1ull << 31);
+}
+inline void knn_self_device(const float* d_x, const float* d_norm, size_t n, size_t D, int num_cus, uint32_t* d_ids, float* d_dist,
+                            bool verbose = false) {
+    if (!knn_sym_wanted(n, D)) {
+        knn_device(d_x, d_norm, n, d_x, d_norm, n, D, true, num_cus, d_ids, d_dist);
+        return;
+    }
+    StageTimer tm{verbose};
+    // 1. thresholds from a sample of the rows
+    const uint32_t ns = (uint32_t)((n + kKnnSymSample - 1) / kKnnSymSample);
+    DevBuf<float> d_tau(n);
+    {
+        DevBuf<uint32_t> d_sid(ns), d_soi(n * kKnnK);
+        DevBuf<float> d_sx((size_t)ns * D), d_sn(ns), d_sod(n * kKnnK);
+        hipLaunchKernelGGL(knn_sym_iota_kernel, dim3(grid_for(ns, 256)), dim3(256), 0, nullptr, d_sid.p, ns, kKnnSymSample);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)std::min<size_t>(ns, (size_t)num_cus * 64)), dim3(64), 0, nullptr, d_x,
+                           d_sid.p, (uint64_t)ns, (uint32_t)D, d_sx.p);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(ns, 256)), dim3(256), 0, nullptr, d_norm, d_sid.p, (uint64_t)ns, d_sn.p);
+        HIP_CHECK(hipGetLastError());
+        knn_device(d_x, d_norm, n, d_sx.p, d_sn.p, ns, D, false, num_cus, d_soi.p, d_sod.p);
+        hipLaunchKernelGGL(knn_sym_tau_kernel, dim3(grid_for(n, 256)), dim3(256), 0, nullptr, d_sod.p, (uint32_t)n, d_tau.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    tm.lap("kNN: thresholds from a 1/16 sample");
+    // 2. the join: every tile once, both sides
+    DevBuf<uint32_t> d_cnt(n), d_cid(n * kKnnSymCap), d_redo(n), d_nredo(1);
+    DevBuf<float> d_cd(n * kKnnSymCap);
+    HIP_CHECK(hipMemset(d_cnt.p, 0, n * 4));
+    HIP_CHECK(hipMemset(d_nredo.p, 0, 4));
+    const uint32_t nblk = (uint32_t)((n + kKnnTile - 1) / kKnnTile);
+    const uint32_t nwg = (nblk + 1) / 2;
+    const uint32_t wg_per_launch = (uint32_t)num_cus * 4u;     // slices, so that no single launch runs for minutes
+    for (uint32_t w0 = 0; w0 < nwg; w0 += wg_per_launch) {
+        KnnSymArgs a{d_x, d_norm, d_tau.p, (uint32_t)n, (uint32_t)D, nblk, w0, d_cnt.p, d_cid.p, d_cd.p};
+        hipLaunchKernelGGL(knn_sym_kernel, dim3(std::min(wg_per_launch, nwg - w0)), dim3(256), 0, nullptr, a);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    tm.lap("kNN: symmetric join");
+    // 3. the best 32 of every row's candidates; rows without enough of them go on the list
+    hipLaunchKernelGGL(knn_sym_select_kernel, dim3((uint32_t)std::min<size_t>(n, (size_t)num_cus * 64)), dim3(64), 0, nullptr, d_cnt.p,
+                       d_cid.p, d_cd.p, (uint32_t)n, d_ids, d_dist, d_redo.p, d_nredo.p);
+    HIP_CHECK(hipGetLastError());
+    uint32_t nredo = 0;
+    HIP_CHECK(hipMemcpy(&nredo, d_nredo.p, 4, hipMemcpyDeviceToHost));
+    tm.lap("kNN: selection");
+    // 4. ... and are answered exactly against every row
+    if (nredo) {
+        DevBuf<float> d_rx((size_t)nredo * D), d_rn(nredo), d_rd((size_t)nredo * kKnnK);
+        DevBuf<uint32_t> d_ri((size_t)nredo * kKnnK);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)std::min<size_t>(nredo, (size_t)num_cus * 64)), dim3(64), 0, nullptr, d_x,
+                           d_redo.p, (uint64_t)nredo, (uint32_t)D, d_rx.p);
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(grid_for(nredo, 256)), dim3(256), 0, nullptr, d_norm, d_redo.p, (uint64_t)nredo, d_rn.p);
+        HIP_CHECK(hipGetLastError());
+        knn_device(d_rx.p, d_rn.p, nredo, d_x, d_norm, n, D, true, num_cus, d_ri.p, d_rd.p, d_redo.p);
+        hipLaunchKernelGGL(knn_sym_scatter_kernel, dim3(grid_for((size_t)nredo * kKnnK, 256)), dim3(256), 0, nullptr, d_redo.p, nredo,
+                           d_ri.p, d_rd.p, d_ids, d_dist);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    if (verbose) fprintf(stderr, "[build] kNN: %u of %zu rows took the fallback\n", nredo, n);
+    tm.lap("kNN: fallback rows");
 }
 
 // rows of `src` (host, `width` floats each) into a zeroed device image with `ld` floats per row
@@ -104,7 +180,7 @@ inline void gpu_knn(const float* q, const float* qnorm, size_t nq, const float* 
     upload_padded(d_x.p, Dk, x, D, n);
     HIP_CHECK(hipMemcpy(d_norm.p, norm_sq, n * 4, hipMemcpyHostToDevice));
     if (self) {
-        knn_device(d_x.p, d_norm.p, n, d_x.p, d_norm.p, n, Dk, true, num_cus, d_oi.p, d_od.p);
+        knn_self_device(d_x.p, d_norm.p, n, Dk, num_cus, d_oi.p, d_od.p, getenv("CPH_BUILD_VERBOSE") != nullptr);
         nq = n;
     } else {
         DevBuf<float> d_q(nq * Dk), d_qn(nq);

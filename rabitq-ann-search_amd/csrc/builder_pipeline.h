@@ -131,12 +131,12 @@ inline void build_graph(HostIndex& hi, BuiltDevice& dev, const float* vecs, size
     {
         DevBuf<float> d_kd(n * kKnnK);
         if (Dk == D) {
-            knn_device(d_x.p, d_norm.p, n, d_x.p, d_norm.p, n, D, true, num_cus, d_knn.p, d_kd.p);
+            knn_self_device(d_x.p, d_norm.p, n, D, num_cus, d_knn.p, d_kd.p, verbose);
         } else {
             DevBuf<float> d_xk(n * Dk);
             HIP_CHECK(hipMemset(d_xk.p, 0, n * Dk * 4));
             HIP_CHECK(hipMemcpy2D(d_xk.p, Dk * 4, d_x.p, D * 4, D * 4, n, hipMemcpyDeviceToDevice));
-            knn_device(d_xk.p, d_norm.p, n, d_xk.p, d_norm.p, n, Dk, true, num_cus, d_knn.p, d_kd.p);
+            knn_self_device(d_xk.p, d_norm.p, n, Dk, num_cus, d_knn.p, d_kd.p, verbose);
         }
     }
     tm.lap("exact 32-NN (MFMA)");

@@ -62,6 +62,7 @@ struct KnnArgs {
     uint32_t exclude_self;         // q == b: row i never lists column i
     uint32_t* out_ids;     // [nq][32] ascending by distance, 0xFFFFFFFF padded
     float* out_dist;       // [nq][32] squared L2, FLT_MAX padded
+    const uint32_t* q_ids; // optional with exclude_self: query row i is base row q_ids[i] (a gathered subset) instead of row i
 };
 
 typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
@@ -107,7 +108,12 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
     const uint32_t row0 = a.row_begin + blockIdx.x * kKnnTile;
     if (row0 >= a.row_end) return;
     const float NEG_INF = -__builtin_inff();
-    if (tid < kKnnTile) { cnt[tid] = 0; sig[tid] = NEG_INF; }
+    __shared__ uint32_t self_s[kKnnTile];                        // the base row a query row must not list (exclude_self)
+    if (tid < kKnnTile) {
+        cnt[tid] = 0; sig[tid] = NEG_INF;
+        const uint32_t qr = row0 + (uint32_t)tid;
+        self_s[tid] = a.q_ids ? a.q_ids[qr < a.nq ? qr : a.nq - 1] : qr;
+    }
 
     const uint32_t D = a.D;                       // multiple of kKnnKC (the host pads)
     const uint32_t nchunk = D / kKnnKC;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void knn_mfma_kernel(KnnArgs a) {
                 const int rlo = wrow + (i & 3) + 8 * (i >> 2);           // C/D layout of the 32x32 MFMA:
                 const int r = rlo + 4 * h;                               // lane half h holds row rlo + 4h
                 const float s = acc[t][i];
-                bool pass = s > sg[i] && !(a.exclude_self && col == row0 + (uint32_t)r);
+                bool pass = s > sg[i] && !(a.exclude_self && col == self_s[r]);
                 if (__ballot(pass) == 0) continue;
                 // the 32 lanes of a half share the row; the two halves take their turns (wave-uniform)
 #pragma unroll

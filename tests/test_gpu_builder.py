@@ -108,6 +108,51 @@ def test_knn_bruteforce_is_exact():
         assert (ids != np.arange(n)[:, None]).all()
 
 
+@pytest.mark.parametrize("n,dim,kind", [(40_000, 96, "gauss"), (33_000, 128, "clustered"), (36_001, 200, "gauss")])
+def test_knn_symmetric_self_join_is_exact(n, dim, kind, tmp_path):
+    """From 32,768 rows on the self-join computes every tile of the distance matrix once (device_knn_sym.h: thresholds
+    from a 1/16 sample, both sides of a tile appended to per-row buffers, selection, exact fallback for the rows whose
+    threshold was too tight).  Checked against float64 on a sample of rows -- distances, the distances of the returned
+    ids, no self, ascending order -- and against the two-pass kernel (CPH_KNN_SYM=0 in a child process: the switch is
+    read once per process): the same id lists wherever the 32nd and 33rd distances are not (nearly) tied."""
+    import subprocess, sys, os
+    import cphnsw_mi355x
+    rng = np.random.default_rng(n + dim)
+    if kind == "gauss":
+        X = rng.standard_normal((n, dim)).astype(np.float32)
+    else:
+        X, _ = sift_like(rng, n, dim, 300)
+    ids, d = cphnsw_mi355x.knn_bruteforce(X)
+    assert (ids != np.arange(n, dtype=np.uint32)[:, None]).all() and (ids < n).all()
+    assert (np.diff(d, axis=1) >= 0).all()
+    rows = rng.integers(0, n, 300)
+    X64 = X.astype(np.float64)
+    for r in rows:
+        dd = ((X64 - X64[r]) ** 2).sum(1)
+        dd[r] = np.inf
+        want = np.sort(dd)[:32]
+        assert np.allclose(d[r], want, rtol=1e-4, atol=1e-3), (r, d[r][:4], want[:4])
+        assert np.allclose(dd[ids[r].astype(np.int64)], want, rtol=1e-4, atol=1e-3), r
+        assert len(set(ids[r].tolist())) == 32
+    # the two-pass kernel on the same input
+    np.save(tmp_path / "x.npy", X)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import cphnsw_mi355x; X = np.load(%r); "
+            "i, d = cphnsw_mi355x.knn_bruteforce(X); np.save(%r, i); np.save(%r, d)"
+            % (os.path.dirname(os.path.dirname(cphnsw_mi355x.__file__)), str(tmp_path / "x.npy"), str(tmp_path / "i.npy"), str(tmp_path / "d.npy")))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, CPH_KNN_SYM="0"))
+    ids0, d0 = np.load(tmp_path / "i.npy"), np.load(tmp_path / "d.npy")
+    assert np.allclose(d, d0, rtol=1e-5, atol=1e-3)
+    differ = (ids != ids0).any(axis=1)
+    if kind == "gauss":
+        assert differ.mean() < 1e-2, differ.mean()          # only where two distances round differently around rank 32
+    for r in np.nonzero(differ)[0][:300]:                   # a different id must be a tie within float32 rounding, never a farther row
+        dd = ((X64 - X64[r]) ** 2).sum(1)
+        dd[r] = np.inf
+        want = np.sort(dd)[:32]
+        for got in (ids[r], ids0[r]):
+            assert np.allclose(np.sort(dd[got.astype(np.int64)]), want, rtol=1e-5, atol=1e-4), (r, kind)
+
+
 @pytest.mark.parametrize("bits,n,dim", [(1, 6000, 128), (2, 6000, 128), (4, 6000, 128), (4, 2500, 960),
                                         (2, 3000, 96), (4, 1200, 10)])
 def test_built_index_is_valid_for_reference_and_search_matches(tmp_path, bits, n, dim):
