@@ -35,6 +35,8 @@ namespace cph {
 constexpr uint32_t kKnnSymSample = 16;   // the seed pass sees every 16th row
 constexpr uint32_t kKnnSymRank = 8;      // tau = distance of the 8th nearest sample row
 constexpr uint32_t kKnnSymCap = 256;     // candidates kept per row (expected ~120, sd ~45)
+constexpr uint32_t kKnnSymQueue = 2048;  // appends a workgroup queues in LDS between two flushes
+constexpr uint32_t kKnnSymFlushAt = 1024;
 
 struct KnnSymArgs {
     const float* x;        // [n][D] rows (zero padded to D, a multiple of 32)
@@ -51,6 +53,11 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
     __shared__ __align__(16) float Qs[2][kKnnTile * kKnnLd];     // double-buffered operand images
     __shared__ __align__(16) float Bs[2][kKnnTile * kKnnLd];
     __shared__ float bn_s[2][256];                               // by tile parity: |c|^2 of the tile's 128 columns, then their thresholds
+    // Appends are queued in LDS and handed to the per-row buffers in batches: the slot of an append is an atomic add WITH a
+    // result, a ~2-us round trip for a wave that has its SIMD to itself, and two tiles in three have one
+    __shared__ uint32_t q_row[kKnnSymQueue], q_id[kKnnSymQueue];
+    __shared__ float q_d[kKnnSymQueue];
+    __shared__ uint32_t q_n;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -61,6 +68,25 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
     const uint32_t nchunk = D / kKnnKC;
     const uint32_t srow = tid >> 3, skq = (tid & 7) * 4;
     const int wrow = wave * 32;
+    if (tid == 0) q_n = 0;
+    // one entry into its row's buffer (the slow, direct way: also taken when the queue is full)
+    auto append = [&](uint32_t row, uint32_t id, float d) {
+        const uint32_t pos = atomicAdd(&a.cnt[row], 1u);
+        if (pos < kKnnSymCap) { a.cid[(size_t)row * kKnnSymCap + pos] = id; a.cd[(size_t)row * kKnnSymCap + pos] = d; }
+    };
+    // whole workgroup, between two barriers of its own: every queued entry to its row, the queue emptied
+    auto flush = [&]() {
+        const uint32_t m = q_n < kKnnSymQueue ? q_n : kKnnSymQueue;
+        for (uint32_t e = tid; e < m; e += 256) append(q_row[e], q_id[e], q_d[e]);
+        __syncthreads();
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+    };
+    auto enqueue = [&](uint32_t row, uint32_t id, float d) {
+        const uint32_t pos = atomicAdd(&q_n, 1u);           // LDS atomic: tens of cycles
+        if (pos < kKnnSymQueue) { q_row[pos] = row; q_id[pos] = id; q_d[pos] = d; }
+        else append(row, id, d);
+    };
 
     for (int phase = 0; phase < 2; ++phase) {
         const uint32_t blk = phase == 0 ? p : a.nblk - 1 - p;
@@ -184,6 +210,9 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             buf ^= 1;
+            // (every wave is past the previous tile's epilogue here and none appends before the next one: q_n is the same
+            // for all of them, the branch is uniform across the workgroup)
+            if (ch == 0 && q_n >= kKnnSymFlushAt) flush();
             // ---- second half ----
             read_ops(buf, 0, op0);
             mfma_half(op1);
@@ -212,27 +241,17 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
                 }
                 if (!__any(lead >= 0.0f)) continue;
                 const uint32_t col = tile * kKnnTile + t * 32 + c;
-                // Slots first, entries second: an append is an atomic add WITH a result, a ~2-us round trip for a wave that has
-                // its SIMD to itself -- taken one by one they cost a third of the join (1.66 s at 1M x 128); issued back to back
-                // for the sub-tile's 16 rows they overlap into one round trip.
-                uint32_t posr[16], posc[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t row = row0 + (uint32_t)(wrow + (i & 3) + 8 * (i >> 2) + 4 * h);
-                    posr[i] = 0xFFFFFFFFu;
-                    posc[i] = 0xFFFFFFFFu;
-                    if (dd[i] <= sg[i] && col != row) posr[i] = atomicAdd(&a.cnt[row], 1u);   // (sg = -inf for rows past the end, d = +inf for columns)
-                    if (dd[i] <= tc && row < a.n) posc[i] = atomicAdd(&a.cnt[col], 1u);       // (tc = -inf on the diagonal and for columns past the end)
-                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const uint32_t row = row0 + (uint32_t)(wrow + (i & 3) + 8 * (i >> 2) + 4 * h);
                     const float d = dd[i] > 0.0f ? dd[i] : 0.0f;
-                    if (posr[i] < kKnnSymCap) { a.cid[(size_t)row * kKnnSymCap + posr[i]] = col; a.cd[(size_t)row * kKnnSymCap + posr[i]] = d; }
-                    if (posc[i] < kKnnSymCap) { a.cid[(size_t)col * kKnnSymCap + posc[i]] = row; a.cd[(size_t)col * kKnnSymCap + posc[i]] = d; }
+                    if (dd[i] <= sg[i] && col != row) enqueue(row, col, d);      // (sg = -inf for rows past the end, d = +inf for columns)
+                    if (dd[i] <= tc && row < a.n) enqueue(col, row, d);          // (tc = -inf on the diagonal and for columns past the end)
                 }
             }
         }
+        __syncthreads();                    // every wave's last epilogue of this row block is in the queue
+        flush();
     }
 }
 
