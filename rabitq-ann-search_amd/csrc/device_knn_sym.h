@@ -49,10 +49,16 @@ struct KnnSymArgs {
     float* cd;             // [n][kKnnSymCap]
 };
 
+// (A variant with two accumulator sets, a finished tile's distance arithmetic running behind the next tile's MFMAs one
+// sub-tile per chunk, was built and measured in round 3: the second set and the arithmetic's operands do not fit next to the
+// operand registers -- 512 registers used, 58 spilled, the previous set shuttled through v_accvgpr moves -- and the join took
+// 2.08 s against 1.37 s at 1M x 128.  profiles/r3b_spilled_beam_experiments.md, section 7.)
+template <int V> struct knn_ic { static constexpr int value = V; };
+
 __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
     __shared__ __align__(16) float Qs[2][kKnnTile * kKnnLd];     // double-buffered operand images
     __shared__ __align__(16) float Bs[2][kKnnTile * kKnnLd];
-    __shared__ float bn_s[2][256];                               // by tile parity: |c|^2 of the tile's 128 columns, then their thresholds
+    __shared__ float bn_s[3][256];                               // by tile index mod 3: |c|^2 of the tile's 128 columns, then their thresholds
     // Appends are queued in LDS and handed to the per-row buffers in batches: the slot of an append is an atomic add WITH a
     // result, a ~2-us round trip for a wave that has its SIMD to itself, and two tiles in three have one
     __shared__ uint32_t q_row[kKnnSymQueue], q_id[kKnnSymQueue];
@@ -111,16 +117,17 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
 
         knn_f32x4 pq[4], pb[4];
         float pbn = 0.0f;
-        uint32_t f_tile = tile0, f_ch = 0;
-        uint32_t f_tile_staged = tile0;
+        uint32_t f_tile = tile0, f_ch = 0, f_slot = 0;     // the chunk the next fetch() brings in; f_slot = (f_tile - tile0) mod 3
+        uint32_t f_slot_staged = 0;
         auto fetch = [&]() {
             const uint32_t k0 = f_ch * kKnnKC;
-            f_tile_staged = f_tile;
+            f_slot_staged = f_slot;
             {   // threads 0..127: |c|^2 of column tid (+inf past the end: d = +inf never passes); 128..255: its threshold
                 const uint32_t col = f_tile * kKnnTile + (tid & (kKnnTile - 1));
                 const uint32_t cc = col < a.n ? col : a.n - 1;
                 const float v = tid < kKnnTile ? a.norm[cc] : a.tau[cc];
-                pbn = col < a.n ? v : (tid < kKnnTile ? __builtin_inff() : NEG_INF);
+                // (the diagonal tile holds (r, c) and (c, r): its row side covers both, its column thresholds are -inf)
+                pbn = tid < kKnnTile ? (col < a.n ? v : __builtin_inff()) : ((col < a.n && f_tile != blk) ? v : NEG_INF);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -130,10 +137,12 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
             }
             const bool wrap = f_ch + 1 == nchunk;
             f_ch = wrap ? 0 : f_ch + 1;
-            f_tile = (wrap && f_tile + 1 < ntile) ? f_tile + 1 : f_tile;
+            const bool next = wrap && f_tile + 1 < ntile;
+            f_tile = next ? f_tile + 1 : f_tile;
+            f_slot = next ? (f_slot == 2 ? 0 : f_slot + 1) : f_slot;
         };
         auto stage = [&](int buf) {
-            bn_s[f_tile_staged & 1][tid] = pbn;
+            bn_s[f_slot_staged][tid] = pbn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 *reinterpret_cast<knn_f32x4*>(&Qs[buf][(srow + 32 * i) * kKnnLd + skq]) = pq[i];
@@ -153,18 +162,60 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
                     o.bv[jj][t] = *reinterpret_cast<const knn_f32x4*>(&Bb[(t * 32 + c) * kKnnLd + 8 * j + 4 * h]);
             }
         };
-        knn_f32x16 acc[4];
-        auto mfma_half = [&](const Ops& o) {
+        knn_f32x16 acc[1][4];
+        auto mfma_half = [&](auto SC, const Ops& o) {
+            constexpr int S = decltype(SC)::value;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].x, o.bv[jj][t].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].y, o.bv[jj][t].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].z, o.bv[jj][t].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].w, o.bv[jj][t].w, acc[t], 0, 0, 0);
+                    acc[S][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].x, o.bv[jj][t].x, acc[S][t], 0, 0, 0);
+                    acc[S][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].y, o.bv[jj][t].y, acc[S][t], 0, 0, 0);
+                    acc[S][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].z, o.bv[jj][t].z, acc[S][t], 0, 0, 0);
+                    acc[S][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.av[jj].w, o.bv[jj][t].w, acc[S][t], 0, 0, 0);
                 }
             }
+        };
+        // "does any of this lane's 16 distances of sub-tile t pass either threshold": max over (threshold - d), >= 0 if so
+        auto lead_of = [&](auto PC, auto TC, uint32_t slot) {
+            constexpr int P = decltype(PC)::value;
+            constexpr int t = decltype(TC)::value;
+            const float nc = bn_s[slot][t * 32 + c];
+            const float tc = bn_s[slot][kKnnTile + t * 32 + c];
+            float lead = NEG_INF;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float dd = __builtin_fmaf(-2.0f, acc[P][t][i], nr[i] + nc);
+                lead = __builtin_fmaxf(lead, __builtin_fmaxf(sg[i], tc) - dd);
+            }
+            return lead;
+        };
+        // the appends of tile `tile` (accumulator set P, norms / thresholds in bn_s[slot]) for the sub-tiles whose lead says so
+        auto appends = [&](auto PC, uint32_t tile, uint32_t slot, const float (&lead)[4]) {
+            constexpr int P = decltype(PC)::value;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!__any(lead[t] >= 0.0f)) continue;
+                const float nc = bn_s[slot][t * 32 + c];
+                const float tc = bn_s[slot][kKnnTile + t * 32 + c];
+                const uint32_t col = tile * kKnnTile + t * 32 + c;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t row = row0 + (uint32_t)(wrow + (i & 3) + 8 * (i >> 2) + 4 * h);
+                    const float dd = __builtin_fmaf(-2.0f, acc[P][t][i], nr[i] + nc);
+                    const float d = dd > 0.0f ? dd : 0.0f;
+                    if (dd <= sg[i] && col != row) enqueue(row, col, d);      // (sg = -inf for rows past the end, d = +inf for columns)
+                    if (dd <= tc && row < a.n) enqueue(col, row, d);          // (tc = -inf on the diagonal and for columns past the end)
+                }
+            }
+        };
+        auto epilogue_now = [&](auto PC, uint32_t tile, uint32_t slot) {
+            float lead[4];
+            lead[0] = lead_of(PC, knn_ic<0>{}, slot);
+            lead[1] = lead_of(PC, knn_ic<1>{}, slot);
+            lead[2] = lead_of(PC, knn_ic<2>{}, slot);
+            lead[3] = lead_of(PC, knn_ic<3>{}, slot);
+            appends(PC, tile, slot, lead);
         };
 
         // prologue: image(0) staged and published, the next chunk in flight, first-half operands in registers
@@ -176,20 +227,21 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
         __syncthreads();
         read_ops(0, 0, op0);
         int buf = 0;
-        for (uint32_t tile = tile0; tile < ntile; ++tile)
-        for (uint32_t ch = 0; ch < nchunk; ++ch) {
+        // one K chunk of the current tile
+        auto chunk_body = [&](auto SC, uint32_t ch) {
+            constexpr int S = decltype(SC)::value;
             if (ch == 0) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+                    for (int i = 0; i < 16; ++i) acc[S][t][i] = 0.0f;
             }
             // ---- first half (see knn_mfma_kernel for the schedule) ----
             __builtin_amdgcn_sched_barrier(0);
             read_ops(buf, 1, op1);
             stage(buf ^ 1);
             fetch();
-            mfma_half(op0);
+            mfma_half(SC, op0);
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -210,12 +262,12 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             buf ^= 1;
-            // (every wave is past the previous tile's epilogue here and none appends before the next one: q_n is the same
+            // (every wave is past the previous tile's appends here and none appends before the next ones: q_n is the same
             // for all of them, the branch is uniform across the workgroup)
             if (ch == 0 && q_n >= kKnnSymFlushAt) flush();
             // ---- second half ----
             read_ops(buf, 0, op0);
-            mfma_half(op1);
+            mfma_half(SC, op1);
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -223,34 +275,16 @@ __global__ __launch_bounds__(256, 1) void knn_sym_kernel(KnnSymArgs a) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 22, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ch + 1 != nchunk) continue;
-
-            // ---- tile finished: both sides of its 4 x (32 x 32) distances against their thresholds -------------------
-            const bool diag = tile == blk;      // the diagonal tile holds (r, c) and (c, r): its row side covers both
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float nc = bn_s[tile & 1][t * 32 + c];
-                const float tc = diag ? NEG_INF : bn_s[tile & 1][kKnnTile + t * 32 + c];
-                // "does any of my 16 distances pass either threshold" as one max-reduction and one compare
-                float lead = NEG_INF;
-                float dd[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    dd[i] = __builtin_fmaf(-2.0f, acc[t][i], nr[i] + nc);
-                    lead = __builtin_fmaxf(lead, __builtin_fmaxf(sg[i], tc) - dd[i]);
-                }
-                if (!__any(lead >= 0.0f)) continue;
-                const uint32_t col = tile * kKnnTile + t * 32 + c;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t row = row0 + (uint32_t)(wrow + (i & 3) + 8 * (i >> 2) + 4 * h);
-                    const float d = dd[i] > 0.0f ? dd[i] : 0.0f;
-                    if (dd[i] <= sg[i] && col != row) enqueue(row, col, d);      // (sg = -inf for rows past the end, d = +inf for columns)
-                    if (dd[i] <= tc && row < a.n) enqueue(col, row, d);          // (tc = -inf on the diagonal and for columns past the end)
-                }
-            }
+        };
+        // slots of the norm / threshold images: tile (tile0 + j) lives in bn_s[j mod 3]
+        uint32_t cslot = 0;
+        for (uint32_t tile = tile0; tile < ntile; ++tile) {
+            for (uint32_t ch = 0; ch < nchunk; ++ch) chunk_body(knn_ic<0>{}, ch);
+            // ---- tile finished: both sides of its 4 x (32 x 32) distances against their thresholds ----
+            epilogue_now(knn_ic<0>{}, tile, cslot);
+            cslot = cslot == 2 ? 0 : cslot + 1;
         }
-        __syncthreads();                    // every wave's last epilogue of this row block is in the queue
+        __syncthreads();                    // every wave's last appends of this row block are in the queue
         flush();
     }
 }
