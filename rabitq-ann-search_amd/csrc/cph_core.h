@@ -61,7 +61,10 @@ inline DevLayout make_dev_layout(uint32_t D, uint32_t BW) {
     L.aux_off = L.codes_bytes;           // multiple of 128
     L.ids_off = L.aux_off + 32 * 16;
     L.count_off = L.ids_off + 32 * 4;
-    L.stride = (L.count_off + 4 + 63) / 64 * 64;
+#ifndef CPH_BLOCK_ALIGN
+#define CPH_BLOCK_ALIGN 64u   // (128 -- a block never straddles one more 128-byte line than it needs -- measured: see DESIGN.md section 6)
+#endif
+    L.stride = (L.count_off + 4 + CPH_BLOCK_ALIGN - 1) / CPH_BLOCK_ALIGN * CPH_BLOCK_ALIGN;
     return L;
 }
 
