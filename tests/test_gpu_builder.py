@@ -108,7 +108,7 @@ def test_knn_bruteforce_is_exact():
         assert (ids != np.arange(n)[:, None]).all()
 
 
-@pytest.mark.parametrize("n,dim,kind", [(40_000, 96, "gauss"), (33_000, 128, "clustered"), (36_001, 200, "gauss")])
+@pytest.mark.parametrize("n,dim,kind", [(40_000, 96, "gauss"), (33_000, 128, "clustered"), (36_001, 200, "gauss"), (33_000, 64, "dups")])
 def test_knn_symmetric_self_join_is_exact(n, dim, kind, tmp_path):
     """From 32,768 rows on the self-join computes every tile of the distance matrix once (device_knn_sym.h: thresholds
     from a 1/16 sample, both sides of a tile appended to per-row buffers, selection, exact fallback for the rows whose
@@ -120,6 +120,10 @@ def test_knn_symmetric_self_join_is_exact(n, dim, kind, tmp_path):
     rng = np.random.default_rng(n + dim)
     if kind == "gauss":
         X = rng.standard_normal((n, dim)).astype(np.float32)
+    elif kind == "dups":
+        # 500 distinct vectors, 66 copies of each: thresholds of zero or of a whole cluster, tiles with thousands of passing
+        # pairs (the LDS queue overflows into direct appends), per-row buffers that overflow (fallback for most rows)
+        X = np.repeat(rng.standard_normal((500, dim)).astype(np.float32), 66, axis=0)[rng.permutation(n)]
     else:
         X, _ = sift_like(rng, n, dim, 300)
     ids, d = cphnsw_mi355x.knn_bruteforce(X)
@@ -134,6 +138,8 @@ def test_knn_symmetric_self_join_is_exact(n, dim, kind, tmp_path):
         assert np.allclose(d[r], want, rtol=1e-4, atol=1e-3), (r, d[r][:4], want[:4])
         assert np.allclose(dd[ids[r].astype(np.int64)], want, rtol=1e-4, atol=1e-3), r
         assert len(set(ids[r].tolist())) == 32
+        if kind == "dups":
+            assert (dd[ids[r].astype(np.int64)] < 1e-3).all()      # 65 copies of itself to choose from
     # the two-pass kernel on the same input
     np.save(tmp_path / "x.npy", X)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import cphnsw_mi355x; X = np.load(%r); "
