@@ -292,7 +292,12 @@ __device__ __forceinline__ uint4 beam_pack(const BeamEntry& e) {
 // LDS read plus one parallel write.  Two LDS round trips instead of one dependent round trip
 // per heap level.
 template <class H>
-__device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lane) {
+__device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lane_in) {
+#ifdef CPH_LAUNDER_HOT      // (A/B switch: the routines of the usual path recompute their lane arithmetic as well -- fewer VGPRs, more instructions)
+    const int lane = opaque_lane(lane_in);
+#else
+    const int lane = lane_in;
+#endif
     const uint32_t len = size - 1;                // heap length once the last element is taken out
     const typename H::E v = h.lds(len);            // the value __adjust_heap re-inserts
     const uint32_t nint = (len - 1) >> 1;         // nodes j < nint have both children below len
@@ -367,7 +372,12 @@ __device__ __forceinline__ void heap_pop_wave(const H& h, uint32_t size, int lan
 // a ballot and a count, and the moves are one parallel write: ancestors 1..m each drop one step along the path, the
 // value lands on p_m.  One LDS read round trip and one write instead of one dependent round trip per heap level.
 template <class H>
-__device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typename H::E v, int lane) {
+__device__ __forceinline__ void heap_push_wave(const H& h, uint32_t hole, typename H::E v, int lane_in) {
+#ifdef CPH_LAUNDER_HOT
+    const int lane = opaque_lane(lane_in);
+#else
+    const int lane = lane_in;
+#endif
     const uint32_t hp = hole + 1;
     const uint32_t depth = 31u - (uint32_t)__builtin_clz(hp);          // ancestors of the leaf (0 for the root)
     const uint32_t t = (uint32_t)lane + 1;                              // lane t - 1 looks at ancestor p_t
@@ -835,7 +845,26 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
-            bl.issue(blk, a.L, lane);
+            // PROBE FIRST (4-bit, D = 128; round 3).  The reference evaluates all 32 neighbours of a block, but only the NEW ones
+            // -- 3.3 of 32 on the SIFT-like benchmark, none in a quarter of the expansions -- have any observable effect.  The
+            // ids (128 B) decide that, so they, the norm and the vector go out here; the codes and aux values -- 2,560 of the
+            // block's 2,752 bytes -- are fetched after the probe, by the lanes of the new neighbours only (both lane halves
+            // of a neighbour; eight neighbours share a 128-byte line, so ~40 % of the lines drop out) and not at all when
+            // nothing is new.  One more dependent round trip in three expansions out of four against ~40 % less traffic:
+            // full queue 16.4 -> 15.3 ms per 100,000 queries, the 10,000-query launch 2.19 -> 2.14 ms, results identical.
+            // Narrow codes keep the block with the ids: their estimator runs under the probe's round trip.
+#ifdef CPH_NO_PROBE_FIRST
+            constexpr bool kProbeFirst = false;
+#else
+            constexpr bool kProbeFirst = BW == 4 && SD == 128;
+#endif
+            if constexpr (kProbeFirst) {
+#pragma unroll
+                for (int kk = 0; kk < BlockLoads<BW, SD>::kCPL; ++kk) bl.c[kk] = make_uint4(0u, 0u, 0u, 0u);
+                bl.aux = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                bl.issue(blk, a.L, lane);
+            }
             __builtin_amdgcn_sched_barrier(0);
             CPH_TICKF(0);
             // ---- the pop, while those loads are in flight.  It needs only the id of the top, which the loads
@@ -875,7 +904,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             float cur_norm = norm_ld;
             float dot_generic = 0.0f;
             if constexpr (SD < 128) dot_generic = bcast_f32(group_dot8_lo(qv, vrow, D, lane & 7));   // its loads, too, go first
-            bl.retire();
+            if constexpr (!kProbeFirst) bl.retire();
             asm volatile("" : "+v"(cur_norm), "+v"(nid) : "v"(touch));
             CPH_TICKF(2);
             const bool valid = nid != kInvalidNode;  // slot < count (set by the repacker)
@@ -1012,6 +1041,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             if (new_mask == 0) {
                 ++st_allseen;
                 continue;
+            }
+            if constexpr (kProbeFirst) {
+                if ((new_mask >> (lane & 31)) & 1u) bl.issue(blk, a.L, lane);    // both lane halves of a new neighbour
             }
             if constexpr (!kSpeculate) estimate();
             if (skipped2) st_skip++;
