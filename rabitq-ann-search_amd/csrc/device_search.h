@@ -856,7 +856,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
 #ifdef CPH_NO_PROBE_FIRST
             constexpr bool kProbeFirst = false;
 #else
+#ifdef CPH_PROBE_FIRST_NARROW    // A/B switch: the narrow codes as well (they then lose the estimator's overlap with the probe)
+            constexpr bool kProbeFirst = SD == 128;
+#else
             constexpr bool kProbeFirst = BW == 4 && SD == 128;
+#endif
 #endif
             if constexpr (kProbeFirst) {
 #pragma unroll
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             // (9 % of the gate workload's expansions are all-seen, 24 % of C2's) and are bound by dependent round trips,
             // not by bandwidth: there the estimator runs BEFORE the probe's result is looked at, under its round trip.
             // The 4-bit kernel keeps the order that skips the arithmetic of all-seen expansions.
-            constexpr bool kSpeculate = BW <= 2;
+            constexpr bool kSpeculate = BW <= 2 && !kProbeFirst;
             if constexpr (kSpeculate) estimate();
             CPH_TICKF(4);
 #if CPH_PHASE_TIMERS + 0 == 2
