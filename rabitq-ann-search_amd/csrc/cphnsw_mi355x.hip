@@ -450,6 +450,12 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     }
     const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
     if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+    if (mode == 2 && h->bits == 4 && h->L.D == 128) {
+        // a handful of queries: latency, not traffic -- the order of loads without the third dependent round trip
+        hipLaunchKernelGGL((search_kernel<4, 128, false>), dim3(grid), dim3(64), lds, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     CPH_LAUNCH(search_kernel, h->bits, h->L.D, dim3(grid), dim3(64), lds, st, a);
 }
 

@@ -644,7 +644,9 @@ __host__ __device__ constexpr int search_waves_per_simd(int sd, int bw) {
     return sd == 128 ? (bw <= 2 ? CPH_SEARCH_WAVES_PER_SIMD_128_NARROW : CPH_SEARCH_WAVES_PER_SIMD_128)
                      : (sd == 1024 ? CPH_SEARCH_WAVES_PER_SIMD_1024 : CPH_SEARCH_WAVES_PER_SIMD);
 }
-template <int BW, int SD>
+// PF: the probe-first order of the loads (see the expansion loop).  The small-batch launch uses the instantiation without it:
+// a handful of queries is a matter of latency, and the third dependent round trip costs a single query 10 % (565 -> 624 us).
+template <int BW, int SD, bool PF = true>
 __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kernel(SearchArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -857,9 +859,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             constexpr bool kProbeFirst = false;
 #else
 #ifdef CPH_PROBE_FIRST_NARROW    // A/B switch: the narrow codes as well (they then lose the estimator's overlap with the probe)
-            constexpr bool kProbeFirst = SD == 128;
+            constexpr bool kProbeFirst = PF && SD == 128;
 #else
-            constexpr bool kProbeFirst = BW == 4 && SD == 128;
+            constexpr bool kProbeFirst = PF && BW == 4 && SD == 128;
 #endif
 #endif
             if constexpr (kProbeFirst) {
