@@ -188,6 +188,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // dword offset of heap index i (kBeamLds <= i < kBeamPaged) inside the slot's pages
 __device__ __forceinline__ uint32_t beam_page_off(uint32_t i) {
