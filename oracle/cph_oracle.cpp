@@ -223,8 +223,16 @@ inline void est_and_lower(const QParams& q, float ip_approx_est, float ip_approx
     *lower = good ? lo : 0.0f;
 }
 
-// fastscan_kernel.hpp:89-194, vector path (count is always 32 on this path; the scalar
-// tail :176-193 is unreachable for count % 8 == 0).
+// fastscan_kernel.hpp:89-194.  Lanes below 8 * (count / 8) take the AVX2 vector path (:138-173, explicit FMA
+// intrinsics); the remainder count % 8 takes the scalar tail (:176-193), which GCC contracts
+// (-ffp-contract=fast) into a DIFFERENT rounding sequence for the inner-product estimate:
+//   vector  ip_approx = fma(A, fs, fma(B, pc, C))
+//   tail    ip_approx = fma(B, pc, A * fs) + C
+// (found by comparing every fused / unfused variant of the tail against the compiled reference,
+// oracle/_ref; the rest of the tail -- affine map, distance, bound -- contracts to the vector path's
+// sequence).  The reference's graphs have count == 32 on every vertex we have seen, but the v2 format
+// allows short lists (fastscan_layout.hpp:51-92) and the search passes batch_count = count
+// (rabitq_search.hpp:152-154), so the tail is part of the path.
 void convert_1bit(const QParams& q, const uint32_t* fs, const float* nop, const float* ip_qo,
                   const float* ip_cp, const uint16_t* pop, int count, float dqp, float* est,
                   float* lower) {
@@ -233,8 +241,10 @@ void convert_1bit(const QParams& q, const uint32_t* fs, const float* nop, const 
         return;
     }
     float s = std::sqrt(dqp);
+    const int vec_end = count & ~7;
     for (int i = 0; i < count; ++i) {
-        float ipa = std::fmaf(q.A, (float)fs[i], std::fmaf(q.B, (float)pop[i], q.C));
+        float ipa = i < vec_end ? std::fmaf(q.A, (float)fs[i], std::fmaf(q.B, (float)pop[i], q.C))
+                                : std::fmaf(q.B, (float)pop[i], q.A * (float)fs[i]) + q.C;
         est_and_lower(q, ipa, ipa, nop[i], ip_qo[i], ip_cp[i], dqp, s, &est[i], &lower[i]);
     }
 }
@@ -265,7 +275,10 @@ void convert_msb(size_t bw, const QParams& q, const uint32_t* msb, const float* 
     }
 }
 
-// fastscan_kernel.hpp:220-346, vector path.
+// fastscan_kernel.hpp:220-346.  Vector path (:277-321) below 8 * (count / 8); scalar tail (:324-345) for the
+// remainder, as GCC compiles it (see convert_1bit):
+//   vector  ip_nbit = fma(A/K, nbit, fma(B/K, wpc, C))     ip_msb = fma(A, msb, fma(B, mpc, C))
+//   tail    ip_nbit = fma(B/K, wpc, (A/K) * nbit) + C      ip_msb = fma(A, msb, B * mpc) + C
 void convert_nbit(size_t bw, const QParams& q, const uint32_t* nb, const uint32_t* msb,
                   const float* nop, const float* ip_qo, const float* ip_cp,
                   const uint16_t* pop, const uint16_t* wpop, int count, float dqp, float* est,
@@ -278,9 +291,16 @@ void convert_nbit(size_t bw, const QParams& q, const uint32_t* nb, const uint32_
         return;
     }
     float s = std::sqrt(dqp);
+    const int vec_end = count & ~7;
     for (int i = 0; i < count; ++i) {
-        float ipn = std::fmaf(An, (float)nb[i], std::fmaf(Bn, (float)wpop[i], q.C));
-        float ipm = std::fmaf(q.A, (float)msb[i], std::fmaf(q.B, (float)pop[i], q.C));
+        float ipn, ipm;
+        if (i < vec_end) {
+            ipn = std::fmaf(An, (float)nb[i], std::fmaf(Bn, (float)wpop[i], q.C));
+            ipm = std::fmaf(q.A, (float)msb[i], std::fmaf(q.B, (float)pop[i], q.C));
+        } else {
+            ipn = std::fmaf(Bn, (float)wpop[i], An * (float)nb[i]) + q.C;
+            ipm = std::fmaf(q.A, (float)msb[i], q.B * (float)pop[i]) + q.C;
+        }
         est_and_lower(q, ipn, ipm, nop[i], ip_qo[i], ip_cp[i], dqp, s, &est[i], &lower[i]);
     }
 }
@@ -909,20 +929,29 @@ int orc_fastscan_vertex(void* h, const uint8_t* lut, const float* qp7, uint32_t 
     const float* ipqo = (const float*)(nb + L.ip_qo);
     const float* ipcp = (const float*)(nb + L.ip_cp);
     const uint16_t* pop = (const uint16_t*)(nb + L.pop);
+    // the epilogues run over the list's own length, as the search calls them (rabitq_search.hpp:152-154): a list whose
+    // length is not a multiple of 8 ends in their scalar tails; outputs behind the list are zero
+    const int bc = (int)std::min<uint32_t>(32, rd<uint32_t>(nb + L.count));
+    std::memset(est, 0, 128); std::memset(lower, 0, 128); std::memset(lower_stage1, 0, 128);
     if (ix->bw == 1) {
         plane_sums(ix->D, lut, nb + L.codes, sums);
         std::memcpy(msb_out, sums, 128);
-        convert_1bit(qp, sums, nop, ipqo, ipcp, pop, 32, dqp, est, lower);
+        convert_1bit(qp, sums, nop, ipqo, ipcp, pop, bc, dqp, est, lower);
         std::memcpy(lower_stage1, lower, 128);
     } else {
         const uint16_t* wpop = (const uint16_t*)(nb + L.wpop);
         uint32_t m2[32];
         msb_sums(ix->D, ix->bw, lut, nb + L.codes, m2);
-        convert_msb(ix->bw, qp, m2, nop, ipqo, ipcp, pop, 32, dqp, lower_stage1);
+        convert_msb(ix->bw, qp, m2, nop, ipqo, ipcp, pop, bc, dqp, lower_stage1);
         nbit_sums(ix->D, ix->bw, lut, nb + L.codes, sums, msb_out);
-        convert_nbit(ix->bw, qp, sums, msb_out, nop, ipqo, ipcp, pop, wpop, 32, dqp, est, lower);
+        convert_nbit(ix->bw, qp, sums, msb_out, nop, ipqo, ipcp, pop, wpop, bc, dqp, est, lower);
     }
     return 0;
+}
+
+int orc_neighbor_count(void* h, uint32_t vertex) {
+    Index* ix = static_cast<Index*>(h);
+    return (int)std::min<uint32_t>(32, rd<uint32_t>(ix->nb(vertex) + ix->L.count));
 }
 
 int orc_exact_l2(void* h, const float* query, const uint32_t* ids, long n, float* out) {

@@ -169,7 +169,8 @@ class CPIndex:
         out = (C.c_uint64 * 12)()
         _lib.check(_lib.lib().cph_last_search_stats(self._h, out))
         keys = ("expansions", "exact_l2", "new_neighbours", "beam_pushes", "stage2_skipped",
-                "rerun_queries", "kernel_us", "expansions_nothing_new", "slots", "capacity")
+                "rerun_queries", "kernel_us", "expansions_nothing_new", "slots", "capacity",
+                "stage2_reruns", "stage2_undecided")
         return dict(zip(keys, [int(x) for x in out]))
 
     def synchronize(self):

@@ -80,6 +80,15 @@ size_t next_pow2(size_t n) {
         HIP_CHECK(hipGetLastError());                                                             \
     } while (0)
 
+// Sets bit 1 of *flags when some vertex' neighbour list has a length that is not a multiple of 8: such a list ends in the
+// reference's scalar tail (device_fastscan.h: TailLanes), which the probe-first search instantiation leaves out.
+__global__ void scan_counts_kernel(const uint8_t* blocks, uint64_t n, uint32_t stride, uint32_t count_off, uint32_t* flags) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t cnt = *reinterpret_cast<const uint32_t*>(blocks + v * stride + count_off);
+    if (cnt & 7u) atomicOr(flags, 2u);
+}
+
 }  // namespace
 
 // One in-flight batch: query staging, outputs, statistics and per-slot scratch.  A handle owns two,
@@ -113,6 +122,7 @@ struct BatchSet {
     bool used = false;        // a batch has been enqueued on this set (ev_done is meaningful)
     uint32_t nq = 0;          // size of that batch
     uint32_t run_slots = 0;   // slots its search launch used
+    uint64_t run_cap = 0;     // per-slot capacity that launch ran with (n + 1 on the full-capacity slots of the small-batch path)
 };
 constexpr int kStatWords = 18;
 constexpr int kMaxBatchSets = 4;
@@ -158,12 +168,20 @@ struct cph_index {
     uint32_t want_slots = 0;
     uint64_t want_cap = 0;
     uint64_t auto_cap = 0;             // grown when a batch had to re-run queries
+    bool pf_off = false;               // probe first switched off: a batch sent > 2 % of its queries to the re-run launch for a stage-2 decision
     std::mutex mu;
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
 };
 
 namespace {
+
+// The batch launch of this index runs the probe-first instantiation of the search kernel (4-bit codes at D = 128): it sees
+// only the new neighbours' codes, so a query whose stage-2 decision needs the others, and every index with short neighbour
+// lists (flags bit 1: scalar tails), goes to the instantiation without it.
+bool probe_first(const cph_index* h) {
+    return h->bits == 4 && h->L.D == 128 && !(h->flags & 2u) && !h->pf_off;
+}
 
 void require_finalized(cph_index* h) {
     // the reference does not check (it would hit the invalid-entry RuntimeError or garbage,
@@ -220,6 +238,16 @@ void upload_feeders(cph_index* h) {
     h->L = make_dev_layout((uint32_t)hi.D, (uint32_t)hi.bw);
     h->sc = hi.consts();
     h->flags = hi.has_dup_neighbors ? 1u : 0u;
+    if (n != 0) {   // bit 1: short lists with a scalar tail (counted on the device: the blocks of a built index never visit the host)
+        DevBuf<uint32_t> d_flag(1);
+        HIP_CHECK(hipMemset(d_flag.p, 0, 4));
+        hipLaunchKernelGGL(scan_counts_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, nullptr, h->d_blocks.p, (uint64_t)n,
+                           h->L.stride, h->L.count_off, d_flag.p);
+        HIP_CHECK(hipGetLastError());
+        uint32_t f = 0;
+        HIP_CHECK(hipMemcpy(&f, d_flag.p, 4, hipMemcpyDeviceToHost));
+        h->flags |= f & 2u;
+    }
     // rotation signs and the scale factors of the query encoder (rabitq_encoder.hpp:37-39)
     h->d_signs.alloc(3 * hi.D);
     HIP_CHECK(hipMemcpy(h->d_signs.p, hi.rot.signs.data(), 3 * hi.D * 4, hipMemcpyHostToDevice));
@@ -275,6 +303,7 @@ void upload_feeders(cph_index* h) {
     }
     for (auto& s : h->sets) release_scratch(s);
     h->auto_cap = 0;
+    h->pf_off = false;
     h->last_search = -1;
 }
 
@@ -316,8 +345,11 @@ BatchSet& next_set(cph_index* h, hipStream_t st) {
     }
     // (either set's finished batch counts: the other set's is the more recent one)
     for (BatchSet& o : h->sets) {
-        if (o.used && o.ev_done && hipEventQuery(o.ev_done) == hipSuccess && o.pin_stats[5] != 0 && o.cap < h->host.n + 1)
+        if (!(o.used && o.ev_done && hipEventQuery(o.ev_done) == hipSuccess)) continue;
+        // [5] = queries re-run, [8] = those of them that were re-run for a stage-2 decision (probe first), not for capacity
+        if (o.pin_stats[5] > o.pin_stats[8] && o.cap < h->host.n + 1)
             h->auto_cap = std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(h->host.n + 1, o.cap * 4));
+        if (o.pin_stats[8] * 50 > o.nq) h->pf_off = true;
     }
     if (s.used) HIP_CHECK(hipStreamWaitEvent(st, s.ev_done, 0));
     return s;
@@ -385,8 +417,9 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
         s.slots = slots;
         s.cap = cap;
     }
-    // the overflow re-run needs room for every vertex: a few full-capacity slots
-    if (cap < n + 1 && s.r_slots == 0) {
+    // the re-run launch (capacity overflows; stage-2 decisions of the probe-first instantiation) needs room for every
+    // vertex: a few full-capacity slots
+    if ((cap < n + 1 || probe_first(h)) && s.r_slots == 0) {
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const uint64_t per = (n + 1) * 4 + ((uint64_t)kBeamPagesDwords + beam_tail_dwords(n + 1)) * 4 + bm_words * 4;
@@ -433,7 +466,7 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
         a.beam_pages = s.d_beam.p;
         a.beam_tail = s.d_beam_tail.p;
         a.log_ids = s.d_logids.p;
-        a.redo = s.cap < h->host.n + 1 ? s.d_redo.p : nullptr;
+        a.redo = (s.cap < h->host.n + 1 || probe_first(h)) ? s.d_redo.p : nullptr;
         a.redo_count = words + 1;
         grid = s.run_slots;
     } else {
@@ -450,8 +483,10 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     }
     const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
     if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
-    if (mode == 2 && h->bits == 4 && h->L.D == 128) {
-        // a handful of queries: latency, not traffic -- the order of loads without the third dependent round trip
+    if ((mode != 0 || !probe_first(h)) && h->bits == 4 && h->L.D == 128) {
+        // a handful of queries: latency, not traffic -- the order of loads without the third dependent round trip.  Also
+        // the instantiation of the re-run launch (it takes the stage-2 decisions the probe-first one hands over) and of an
+        // index with short neighbour lists (flags bit 1): it evaluates their scalar tails.
         hipLaunchKernelGGL((search_kernel<4, 128, false>), dim3(grid), dim3(64), lds, st, a);
         HIP_CHECK(hipGetLastError());
         return;
@@ -518,6 +553,7 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     ensure_scratch(h, s, slots, cap, st);
     slots = std::min(slots, s.slots);
     s.run_slots = slots;
+    s.run_cap = s.cap;
     s.nq = nq;
     // closest-entry-first launch order (device_encode.h) when the batch outnumbers the slots
     const uint32_t* d_order = nullptr;
@@ -528,13 +564,15 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
     }
     uint32_t* d_count = d_count_out ? d_count_out : s.d_count.p;
     HIP_CHECK(hipEventRecord(s.ev0, st));
-    if (s.cap < n + 1 && nq <= s.r_slots && !h->want_cap && !h->want_slots) {   // (explicit search params keep the general path)
+    const bool rerun = s.cap < n + 1 || probe_first(h);
+    if (rerun && nq <= s.r_slots && !h->want_cap && !h->want_slots) {   // (explicit search params keep the general path)
         // a handful of queries: straight onto the full-capacity slots -- one launch, nothing can overflow
         s.run_slots = nq;
+        s.run_cap = n + 1;
         launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 2, st);
     } else {
         launch_search(h, s, nq, k, d_ids, d_dist, d_count, d_order, 0, st);
-        if (s.cap < n + 1) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st);
+        if (rerun) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st);
     }
     HIP_CHECK(hipEventRecord(s.ev1, st));
     // the statistics block lands in pinned host memory; it is only read when somebody asks
@@ -1020,7 +1058,11 @@ int cph_last_search_stats(cph_index* h, uint64_t out[12]) {
         out[6] = (uint64_t)(ms * 1000.0);
         out[7] = s.pin_stats[7];
         out[8] = s.run_slots;
-        out[9] = s.cap;
+        out[9] = s.run_cap;
+#if !defined(CPH_PHASE_TIMERS) && !defined(CPH_TRAFFIC_STATS)
+        out[10] = s.pin_stats[8];
+        out[11] = s.pin_stats[9];
+#endif
 #if CPH_PHASE_TIMERS + 0 == 2
         fprintf(stderr, "[fine cycles] head+issue=%llu pop=%llu block_wait=%llu probe_issue+exact+nnpush=%llu estimator=%llu probe_wait=%llu mark+cand=%llu pushes+tail=%llu\n",
                 s.pin_stats[8], s.pin_stats[9], s.pin_stats[10], s.pin_stats[11], s.pin_stats[12], s.pin_stats[13], s.pin_stats[14], s.pin_stats[15]);

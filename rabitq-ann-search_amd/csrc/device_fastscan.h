@@ -258,6 +258,48 @@ __device__ __forceinline__ void load_block(const uint8_t* __restrict__ blk, cons
     b.reduce(blk, L, qm, lane, o);
 }
 
+// ---- short neighbour lists: the reference's scalar tails ---------------------------------------
+// The epilogues convert_to_distances_with_bounds / convert_nbit_to_distances_with_bounds take the AVX2 vector path for
+// lanes below 8 * (count / 8) and a scalar loop for the remainder (fastscan_kernel.hpp:174-193, :324-345).  GCC
+// contracts that loop into a different rounding sequence for the inner-product estimates (found against the compiled
+// reference, pinned by tests/golden F/../c<count> vectors; see oracle/cph_oracle.cpp convert_1bit / convert_nbit):
+//     vector  fma(A, s, fma(B, pc, C))            tail, N-bit and 1-bit sums   fma(B, pc, A * s) + C
+//                                                 tail, plane-0 (msb) bound    fma(A, s, B * pc) + C
+// and to the vector path's sequence for everything behind them.  count is the number of valid ids of the block (the
+// repacker sets slots >= count to kInvalidNode); `any` is wave-uniform, so full blocks -- every block the reference's
+// builder and ours write -- pay one scalar branch.
+struct TailLanes {
+    bool any;    // count % 8 != 0 (wave-uniform)
+    bool mine;   // this lane's neighbour index >= 8 * (count / 8)
+};
+// valid: this lane's neighbour slot holds an id.  Both lane halves carry neighbour (lane & 31): the low half's ballot.
+__device__ __forceinline__ TailLanes tail_lanes(bool valid, int lane) {
+    const uint32_t count = (uint32_t)__popc((uint32_t)(__ballot(valid) & 0xFFFFFFFFull));
+    TailLanes t;
+    t.any = (count & 7u) != 0u;
+    t.mine = (uint32_t)(lane & 31) >= (count & ~7u);
+    return t;
+}
+__device__ __forceinline__ TailLanes no_tail() { return TailLanes{false, false}; }
+// A * s + B * pc + C as the vector path / the scalar tail of the N-bit (and 1-bit) estimate evaluates it
+__device__ __forceinline__ float ip_approx_est(float A, float s, float B, float pc, float C, const TailLanes& t) {
+    float r = __fmaf_rn(A, s, __fmaf_rn(B, pc, C));
+    if (__builtin_expect(t.any, 0)) {
+        const float u = __fmaf_rn(B, pc, A * s) + C;
+        r = t.mine ? u : r;
+    }
+    return r;
+}
+// ... and of the plane-0 numerator of the stage-2 lower bound (N-bit only; the 1-bit bound shares the estimate's)
+__device__ __forceinline__ float ip_approx_msb(float A, float s, float B, float pc, float C, const TailLanes& t) {
+    float r = __fmaf_rn(A, s, __fmaf_rn(B, pc, C));
+    if (__builtin_expect(t.any, 0)) {
+        const float u = __fmaf_rn(A, s, B * pc) + C;
+        r = t.mine ? u : r;
+    }
+    return r;
+}
+
 // Shared tail of the AVX2 vector paths fastscan_kernel.hpp:148-169 / :287-317.
 __device__ __forceinline__ void est_and_lower(const QP& q, float ip_est_approx, float ip_lb_approx,
                                               float nop, float ip_qo, float ip_cp, float dqp,
@@ -301,21 +343,22 @@ __device__ __forceinline__ float stage1_lower(const QP& q, const LaneEst& v, flo
 // Stage-2 (full) estimate + lower bound.
 template <int BW>
 __device__ __forceinline__ void stage2_est(const QP& q, const LaneEst& v, float dqp,
-                                           float sqrt_dqp, float& est, float& lower) {
+                                           float sqrt_dqp, float& est, float& lower,
+                                           const TailLanes& tl) {
     if (dqp < kEpsSmall) {  // fastscan_kernel.hpp:112-119 / :249-256 (scalar, fused by GCC)
         est = __fmaf_rn(v.nop, v.nop, dqp);
         lower = 0.0f;
         return;
     }
     if constexpr (BW == 1) {
-        float ipa = __fmaf_rn(q.A, (float)v.nbit, __fmaf_rn(q.B, (float)v.pop, q.C));
+        float ipa = ip_approx_est(q.A, (float)v.nbit, q.B, (float)v.pop, q.C, tl);
         est_and_lower(q, ipa, ipa, v.nop, v.ip_qo, v.ip_cp, dqp, sqrt_dqp, est, lower);
     } else {
         constexpr float K = (float)((1u << BW) - 1);
         constexpr float invK = 1.0f / K;
         float An = q.A * invK, Bn = q.B * invK;
-        float ipn = __fmaf_rn(An, (float)v.nbit, __fmaf_rn(Bn, (float)v.wpop, q.C));
-        float ipm = __fmaf_rn(q.A, (float)v.msb, __fmaf_rn(q.B, (float)v.pop, q.C));
+        float ipn = ip_approx_est(An, (float)v.nbit, Bn, (float)v.wpop, q.C, tl);
+        float ipm = ip_approx_msb(q.A, (float)v.msb, q.B, (float)v.pop, q.C, tl);
         est_and_lower(q, ipn, ipm, v.nop, v.ip_qo, v.ip_cp, dqp, sqrt_dqp, est, lower);
     }
 }
@@ -334,11 +377,11 @@ __device__ __forceinline__ void stage2_est(const QP& q, const LaneEst& v, float 
 // Requires dqp >= kEpsSmall (the caller tests that wave-uniform fact).
 template <int BW>
 __device__ __forceinline__ void lower_bounds_split(const QP& q, const LaneEst& v, float dqp, float sqrt_dqp,
-                                                   int lane, float& lo_stage1, float& lo_stage2) {
+                                                   int lane, float& lo_stage1, float& lo_stage2, const TailLanes& tl) {
     static_assert(BW >= 2, "N-bit path");
     const float invk = 1.0f / 3.0f;
-    const float n1 = __fmaf_rn(q.B * invk, (float)v.pop, (q.A * invk) * (float)v.msb2) + q.C;
-    const float n2 = __fmaf_rn(q.A, (float)v.msb, __fmaf_rn(q.B, (float)v.pop, q.C));
+    const float n1 = __fmaf_rn(q.B * invk, (float)v.pop, (q.A * invk) * (float)v.msb2) + q.C;   // (a scalar loop: no tail of its own)
+    const float n2 = ip_approx_msb(q.A, (float)v.msb, q.B, (float)v.pop, q.C, tl);
     const float num = lane >= 32 ? n2 : n1;
     const float ipq = (v.ip_qo < q.floor) ? q.floor : v.ip_qo;
     float e = (num - v.ip_cp) / ipq;
@@ -356,12 +399,12 @@ __device__ __forceinline__ void lower_bounds_split(const QP& q, const LaneEst& v
 
 // The estimate half of stage2_est / est_and_lower (BW >= 2), for callers that took the bounds from lower_bounds_split.
 template <int BW>
-__device__ __forceinline__ float stage2_est_only(const QP& q, const LaneEst& v, float dqp) {
+__device__ __forceinline__ float stage2_est_only(const QP& q, const LaneEst& v, float dqp, const TailLanes& tl) {
     static_assert(BW >= 2, "N-bit path");
     if (dqp < kEpsSmall) return __fmaf_rn(v.nop, v.nop, dqp);
     constexpr float K = (float)((1u << BW) - 1);
     constexpr float invK = 1.0f / K;
-    const float ipn = __fmaf_rn(q.A * invK, (float)v.nbit, __fmaf_rn(q.B * invK, (float)v.wpop, q.C));
+    const float ipn = ip_approx_est(q.A * invK, (float)v.nbit, q.B * invK, (float)v.wpop, q.C, tl);
     const float ipq = vmaxf(v.ip_qo, q.floor);
     float e = (ipq > kEpsMedium) ? (ipn - v.ip_cp) / ipq : 0.0f;
     e = __fmaf_rn(q.affine_a, e, q.affine_b);

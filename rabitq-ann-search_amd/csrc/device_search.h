@@ -41,7 +41,7 @@ struct SearchArgs {
     const float* norm_sq;   // [n]
     uint64_t n;
     DevLayout L;
-    uint32_t flags;         // bit 0: some vertex repeats a neighbour id
+    uint32_t flags;         // bit 0: some vertex repeats a neighbour id; bit 1: some list's length is not a multiple of 8
     // encoded queries
     const float* queries;   // [nq][D] zero-padded
     const uint4* qmasks;    // [nq][PW]
@@ -741,8 +741,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
         // uniform state
         uint32_t log_count = 0;
         int slack_batch = 0;
-        bool overflow = false, wipe = false;
+        bool overflow = false, wipe = false, stage2_redo = false;
         uint32_t st_exp = 0, st_exact = 0, st_new = 0, st_push = 0, st_skip = 0, st_allseen = 0;
+        // probe first only: expansions where the reference's stage-2 decision is unobservable and was left open (the reference
+        // may have skipped stage 2 there or not -- st_skip counts the skips that were decided)
+        uint32_t st_undecided = 0;
 #ifdef CPH_TRAFFIC_STATS
         // diagnostic build only: what the spilled beam and the estimated-set probe touch (stats[8..15])
         unsigned long long trf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -977,36 +980,66 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             }
             // ---- FastScan estimates (:159-206) ----------------------------------------
             float est = 0.0f, lower = 0.0f;
-            bool skipped2 = false;
-            auto estimate = [&]() {
+            bool skipped2 = false, undecided2 = false;
+            // a list shorter than 32 whose length is not a multiple of 8 ends in the reference's scalar tail
+            // (device_fastscan.h: TailLanes); wave-uniform, never taken on graphs the builders write.  The probe-first
+            // instantiation sits on its register limit and is only launched on indexes without such lists (the loader
+            // knows: SearchArgs::flags bit 1 sends the others to the instantiation without it).
+            const TailLanes tl = kProbeFirst ? no_tail() : tail_lanes(valid, lane);
+            // `fetched`: the lanes whose codes and aux values bl holds -- all of them, or (probe first) the new ones.
+            // Returns false when the reference's stage-2 decision cannot be taken from the fetched lanes (probe first only).
+            auto estimate = [&](bool fetched) -> bool {
                 LaneEst v;
-                bl.reduce(blk, a.L, qm, lane, v);
                 const float dqp = exact_dist;
                 const float sq = __builtin_sqrtf(dqp);
+                bl.reduce(blk, a.L, qm, lane, v);
                 if constexpr (BW == 1) {
-                    stage2_est<1>(qp, v, dqp, sq, est, lower);
+                    stage2_est<1>(qp, v, dqp, sq, est, lower, tl);
                 } else {
                     // both lower bounds at once, one per lane half (see lower_bounds_split); dqp is the popped vertex's
                     // distance, the same in every lane
                     float lo1 = 0.0f, lo2 = 0.0f;
-                    if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2);
-                    bool surv = (nn_sz < k) || (valid && lo1 < worst0);
-                    if (__any(surv)) {
-                        est = stage2_est_only<BW>(qp, v, dqp);
+                    if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2, tl);
+                    // any_survivor (:178-187) ranges over ALL the list's neighbours, estimated before or not
+#ifdef CPH_AB_NOEXPECT
+                    if (nn_sz < k || __any(fetched && valid && lo1 < worst0)) {
+#else
+                    if (__builtin_expect(nn_sz < k || __any(fetched && valid && lo1 < worst0), 1)) {
+#endif
+                        est = stage2_est_only<BW>(qp, v, dqp, tl);
                         lower = lo2;
-                    } else {
+                    } else if constexpr (!kProbeFirst) {            // the reference's skipped batch (:201-205)
                         est = FMAX;
                         lower = lo1;
                         skipped2 = true;
+                    } else {
+                        // Probe first: only the NEW neighbours' codes are here, and none of them survives stage 1.
+                        // Whether the reference runs stage 2 then depends on the bounds of neighbours it will skip
+                        // anyway (:227) -- which matters only if a new neighbour would ACT on its stage-2 values where
+                        // the skipped batch (est = FLT_MAX, lower = stage-1 bound >= worst) makes it do nothing: the two
+                        // bounds have different numerators (2 S0 + S1 over 3 against S0) and are not ordered.  No
+                        // rerank can happen before such a neighbour's turn without being such an action itself, so the
+                        // thresholds of the loop's entry decide: if no new neighbour passes them, both branches leave
+                        // the heaps alone and the block's other codes are never needed.  Else the query is handed to
+                        // the re-run launch, whose instantiation fetches whole blocks and takes the reference's
+                        // decision on the real bounds.  (The stage-1 bounds are loose -- the reference itself never
+                        // skips a batch on its own graphs, SURVEY F4 -- so neither happens outside the fixtures that
+                        // force it: 0 of 2.65 M expansions on the C2 benchmark.)
+                        est = stage2_est_only<BW>(qp, v, dqp, tl);
+                        lower = lo2;
+                        const bool acts = fetched && !(lo2 >= worst0) && (est < worst0 || est < gamma_q * worst0);
+                        if (__any(acts)) return false;
+                        undecided2 = true;
                     }
                 }
+                return true;
             };
             // Narrow codes (1- and 2-bit) estimate poorly, so their searches run long, almost always find something new
             // (9 % of the gate workload's expansions are all-seen, 24 % of C2's) and are bound by dependent round trips,
             // not by bandwidth: there the estimator runs BEFORE the probe's result is looked at, under its round trip.
             // The 4-bit kernel keeps the order that skips the arithmetic of all-seen expansions.
             constexpr bool kSpeculate = BW <= 2 && !kProbeFirst;
-            if constexpr (kSpeculate) estimate();
+            if constexpr (kSpeculate) estimate(true);
             CPH_TICKF(4);
 #if CPH_PHASE_TIMERS + 0 == 2
             asm volatile("" : "+v"(old_bits));
@@ -1050,10 +1083,14 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 continue;
             }
             if constexpr (kProbeFirst) {
-                if ((new_mask >> (lane & 31)) & 1u) bl.issue(blk, a.L, lane);    // both lane halves of a new neighbour
+                const bool fetch = ((new_mask >> (lane & 31)) & 1u) != 0u;       // both lane halves of a new neighbour
+                if (fetch) bl.issue(blk, a.L, lane);
+                if (__builtin_expect(!estimate(fetch), 0)) { overflow = true; stage2_redo = true; break; }
+            } else if constexpr (!kSpeculate) {
+                estimate(true);
             }
-            if constexpr (!kSpeculate) estimate();
             if (skipped2) st_skip++;
+            if (undecided2) st_undecided++;
 
             CPH_TICK(2);
             const bool warmup = nn_sz < k;  // (:210)
@@ -1246,6 +1283,10 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             atomicAdd(&stats[3], (unsigned long long)st_push);
             atomicAdd(&stats[4], (unsigned long long)st_skip);
             atomicAdd(&stats[7], (unsigned long long)st_allseen);
+#if !defined(CPH_PHASE_TIMERS) && !defined(CPH_TRAFFIC_STATS)
+            if (stage2_redo) atomicAdd(&stats[8], 1ull);          // queries handed to the re-run launch for a stage-2 decision
+            if (st_undecided) atomicAdd(&stats[9], (unsigned long long)st_undecided);
+#endif
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tph[i]);
 #endif

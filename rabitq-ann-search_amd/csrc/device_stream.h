@@ -60,12 +60,13 @@ __global__ __launch_bounds__(256) void fastscan_stream_kernel(StreamArgs a) {
         LaneEst v;
         cur.reduce(blk, a.L, qm, lane, v);
         float est, lower;
+        const TailLanes tl = tail_lanes(cur_id != kInvalidNode, lane);     // short lists: the reference's scalar tails
         if constexpr (BW == 1) {
-            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower, tl);
             acc += est + lower;
         } else {
             float lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
-            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower, tl);
             acc += est + lower + lo1;
         }
         if (cur_id == kInvalidNode) acc = 0.0f;  // the neighbour ids are part of the unit of work
@@ -136,12 +137,20 @@ __global__ __launch_bounds__(256) void fastscan_stream_pair_kernel(StreamArgs a)
         v.pop = cur.aux.w & 0xFFFFu;
         v.wpop = cur.aux.w >> 16;
         float est, lower;
+        // short lists (one block per lane half here, so each half counts its own ids)
+        TailLanes tl;
+        {
+            const unsigned long long vm = __ballot(live && cur.id != kInvalidNode);
+            const uint32_t count = (uint32_t)__popc((uint32_t)(h ? vm >> 32 : vm & 0xFFFFFFFFull));
+            tl.any = __any((count & 7u) != 0u);
+            tl.mine = (uint32_t)i >= (count & ~7u);
+        }
         if constexpr (BW == 1) {
-            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+            stage2_est<1>(a.qp, v, a.dqp, sq, est, lower, tl);
             if (live) acc += est + lower;
         } else {
             const float lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
-            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower, tl);
             if (live) acc += est + lower + lo1;
         }
         if (live && cur.id == kInvalidNode) acc = 0.0f;    // the neighbour ids are part of the unit of work
@@ -183,14 +192,15 @@ __global__ __launch_bounds__(64) void block_hook_kernel(BlockHookArgs a) {
     const bool valid = reinterpret_cast<const uint32_t*>(a.blk + a.L.ids_off)[lane & 31] != kInvalidNode;
     const float sq = __builtin_sqrtf(a.dqp);
     float est, lower, lo1;
+    const TailLanes tl = tail_lanes(valid, lane);
     if constexpr (BW == 1) {
-        stage2_est<1>(a.qp, v, a.dqp, sq, est, lower);
+        stage2_est<1>(a.qp, v, a.dqp, sq, est, lower, tl);
         lo1 = lower;
     } else {
         lo1 = stage1_lower<BW>(a.qp, v, a.dqp, sq);
         bool surv = (!a.nn_full) || (valid && lo1 < a.worst);
         if (__any(surv)) {
-            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower);
+            stage2_est<BW>(a.qp, v, a.dqp, sq, est, lower, tl);
         } else {
             est = 3.402823466e+38f;
             lower = lo1;

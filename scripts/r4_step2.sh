@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 4, step 2: stage-2 decisions of the probe-first kernel handed to the re-run launch: parity, then C2 kernel A/B vs round 3
+export TMPDIR=/tmp
+O=gpurun_out/r4_step2; mkdir -p $O
+timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu -s > $O/pytest.log 2>&1; rc=$?; grep -E "bignop general|trajectory:" $O/pytest.log | cut -c1-400; tail -3 $O/pytest.log; [ $rc -eq 0 ] || exit 1
+python3 bench.py --config c2 --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/prep_c2.json 2> $O/prep_c2.err || { tail -5 $O/prep_c2.err; exit 1; }
+python3 scripts/ab_libs.py --config c2 --rounds 3 product build/libcph_r3.so | tee $O/ab_c2.txt
+python3 scripts/ab_libs.py --config c2 --nq 100000 --rounds 2 product build/libcph_r3.so | tee $O/ab_c2_100k.txt

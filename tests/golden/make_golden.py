@@ -5,7 +5,9 @@ Needs oracle/_ref (``make -C oracle ref``), i.e. /root/reference.  Everything wr
 is data: index files saved by the reference's own ``CPIndex.save`` (gzip-compressed), the
 seeded inputs, and the outputs the reference produced for them.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # re-uses the committed idx_*.idx.gz files
+    python tests/golden/make_golden.py --rebuild  # builds new ones (the build is not reproducible across
+                                                  # thread counts, SURVEY F6: every S/ vector changes with it)
 
 Outputs (tests/golden/):
     idx_<name>_b<bits>.idx.gz   reference-built v2 index files
@@ -17,6 +19,8 @@ Key scheme in golden.npz:
     S/<name>/b<bits>/<variant>/k<k>/d     reference search_batch dists (float32 [nq,k])
     E/<D>/<dim>/{q,lut,coeffs,rot}        query-encoder vectors
     F/<D>/b<bits>/...                     FastScan block vectors (sums + fp32 epilogues)
+    F/<D>/b<bits>/c<count>/{est,lower,lower1}  the same epilogues called with count = 5, 13, 29: the scalar tails
+                                          for count % 8 != 0 (lanes >= count are zero)
     X/<D>/{a,b,dot,l2}                    exact arithmetic vectors
 Variants are calibration/graph patches applied to the index file bytes (tests apply the
 same patch with tests/golden_util.py), so the fixture set stays small while still covering
@@ -31,7 +35,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from golden_util import DATASETS, VARIANTS, KS, make_dataset, apply_variant  # noqa: E402
+from golden_util import DATASETS, VARIANTS, KS, SHORT_COUNTS, make_dataset, apply_variant  # noqa: E402
 from oracle_lib import RefHooks, ref_module  # noqa: E402
 
 
@@ -49,15 +53,19 @@ def main():
         X, Q = make_dataset(name)
         out[f"Q/{name}"] = Q
         for bits in spec["bits"]:
-            idx = m.CPIndex(spec["dim"], bits)
-            idx.build(X)
-            idx.finalize()
-            raw = os.path.join(tmp, f"idx_{name}_b{bits}.idx")
-            idx.save(raw)
-            data = open(raw, "rb").read()
-            with gzip.GzipFile(os.path.join(HERE, f"idx_{name}_b{bits}.idx.gz"), "wb",
-                               compresslevel=9, mtime=0) as g:
-                g.write(data)
+            gz = os.path.join(HERE, f"idx_{name}_b{bits}.idx.gz")
+            if os.path.exists(gz) and "--rebuild" not in sys.argv:
+                with gzip.open(gz, "rb") as g:
+                    data = g.read()
+            else:
+                idx = m.CPIndex(spec["dim"], bits)
+                idx.build(X)
+                idx.finalize()
+                raw = os.path.join(tmp, f"idx_{name}_b{bits}.idx")
+                idx.save(raw)
+                data = open(raw, "rb").read()
+                with gzip.GzipFile(gz, "wb", compresslevel=9, mtime=0) as g:
+                    g.write(data)
             for vname in spec["variants"]:
                 patched = apply_variant(data, vname, spec, bits)
                 p = os.path.join(tmp, f"idx_{name}_b{bits}_{vname}.idx")
@@ -142,6 +150,21 @@ def main():
                         est[a, c, i], lower[a, c, i], lower1[a, c, i] = e, lo, lo1
             out[f"{key}/sums"], out[f"{key}/msb"], out[f"{key}/msb2"] = sums, msb, msb2
             out[f"{key}/est"], out[f"{key}/lower"], out[f"{key}/lower1"] = est, lower, lower1
+            # the same blocks with short neighbour lists: count % 8 != 0 reaches the scalar tails
+            for cnt in SHORT_COUNTS:
+                ec, lc, l1c = np.zeros_like(est), np.zeros_like(est), np.zeros_like(est)
+                for i in range(nblk):
+                    for a, qp in enumerate(qps):
+                        for c, dqp in enumerate(dqps):
+                            if bits == 1:
+                                e, lo = r.convert_1bit(D, qp, sums[i], nop[i], ipqo[i], ipcp[i], pop[i], dqp, cnt)
+                                lo1 = lo
+                            else:
+                                lo1 = r.convert_msb(D, bits, qp, msb2[i], nop[i], ipqo[i], ipcp[i], pop[i], dqp, cnt)
+                                e, lo = r.convert_nbit(D, bits, qp, sums[i], msb[i], nop[i], ipqo[i], ipcp[i],
+                                                       pop[i], wpop[i], dqp, cnt)
+                            ec[a, c, i, :cnt], lc[a, c, i, :cnt], l1c[a, c, i, :cnt] = e[:cnt], lo[:cnt], lo1[:cnt]
+                out[f"{key}/c{cnt}/est"], out[f"{key}/c{cnt}/lower"], out[f"{key}/c{cnt}/lower1"] = ec, lc, l1c
 
     for D in (16, 128, 1024):
         a = (rng.standard_normal((16, D)) * 50).astype(np.float32)

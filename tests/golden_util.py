@@ -18,13 +18,13 @@ CALIB_OFF = 68  # CalibrationSnapshot offset in the v2 file
 DATASETS = {
     # name: n, dim, D (padded), bit-widths, kind, seed, variants
     "g128": dict(n=400, dim=128, D=128, bits=(1, 2, 4), kind="gauss", seed=101,
-                 variants=("plain", "gamma", "affine", "bignop")),
+                 variants=("plain", "gamma", "affine", "bignop", "shortcount")),
     "sift96": dict(n=400, dim=96, D=128, bits=(4,), kind="sift", seed=102,
                    variants=("plain", "gamma")),
     "g16": dict(n=300, dim=10, D=16, bits=(1, 2, 4), kind="gauss", seed=103,
-                variants=("plain", "gamma_tight")),
+                variants=("plain", "gamma_tight", "shortcount")),
     "g1024": dict(n=160, dim=960, D=1024, bits=(2,), kind="gauss", seed=104,
-                  variants=("plain", "affine")),
+                  variants=("plain", "affine", "shortcount")),
 }
 NQ = 24
 
@@ -39,7 +39,14 @@ VARIANTS = {
                    gamma_max=2.5, gamma_beta=1.0, gamma_warmup=8, slack=[-0.05, 0.0, 0.02]),
     # every 3rd vertex gets nop=500 for all 32 neighbours -> stage-2 skip branch
     "bignop": dict(bignop=(3, 500.0)),
+    # every 3rd vertex' neighbour list is cut short (count patched; the slots behind it keep their stale ids, as a
+    # re-pruned list does, graph/graph_refinement.hpp:46-47): the scalar tails of the epilogues for count % 8 != 0
+    # (distance/fastscan_kernel.hpp:174-193, :324-345), batch_count < 32 (search/rabitq_search.hpp:152-154) and the
+    # empty list (:137).  With gamma finite so that the estimates of the tail lanes decide something.
+    "shortcount": dict(shortcount=(3, (0, 5, 13, 29, 31)), search_gamma=1.2, gamma_max=1.8, gamma_beta=0.5,
+                       gamma_warmup=4),
 }
+SHORT_COUNTS = (5, 13, 29)   # F/ vectors: counts with a scalar tail (count % 8 != 0)
 
 
 def sift_like(rng, n, dim, ncl=40):
@@ -63,17 +70,26 @@ def make_dataset(name):
 
 def vertex_layout(D, bits):
     """(vertex_bytes, nb_off, nop_off) of VertexSearchData<D,32,bits>."""
+    return vertex_layout_full(D, bits)[:3]
+
+
+def vertex_layout_full(D, bits):
+    """(vertex_bytes, nb_off, nop_off, count_off): count_off = offset of `count` inside the neighbour block."""
     def up(x, a):
         return (x + a - 1) // a * a
     words = (D + 63) // 64
     code = up(up(bits * words * 8, 64) + 8, 64)
     codes = bits * up((D // 8) * 32, 64)
     o = codes + 3 * 128 + 64 + (64 if bits > 1 else 0) + 128 + 4
-    return code + up(o, 64), code, codes
+    return code + up(o, 64), code, codes, o - 4
 
 
 def apply_variant(data, vname, spec, bits):
-    kw = VARIANTS[vname]
+    return apply_patch(data, VARIANTS[vname], spec, bits)
+
+
+def apply_patch(data, kw, spec=None, bits=None):
+    """Calibration / graph patches on the bytes of a v2 index file (spec and bits only for the graph patches)."""
     b = bytearray(data)
     for k, v in kw.items():
         if k in _F:
@@ -93,6 +109,15 @@ def apply_variant(data, vname, spec, bits):
             for vtx in range(0, n, every):
                 off = base + vtx * vb + nb_off + nop_off
                 b[off:off + 128] = blob
+        elif k == "shortcount":
+            every, counts = v
+            n, dim, D = spec["n"], spec["dim"], spec["D"]
+            vb, nb_off, _, cnt_off = vertex_layout_full(D, bits)
+            base = 68 + 248 + 72 + dim * 4 + n * 4 + n * 4 + n * D * 4
+            for j, vtx in enumerate(range(1, n, every)):
+                off = base + vtx * vb + nb_off + cnt_off
+                old, = struct.unpack_from("<I", b, off)
+                struct.pack_into("<I", b, off, min(old, counts[j % len(counts)]))
     return bytes(b)
 
 

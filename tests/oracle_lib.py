@@ -251,6 +251,11 @@ class OracleIndex:
           est, lo, lo1)
         return sums, msb, est, lo, lo1
 
+    def neighbor_count(self, vertex):
+        f = self.o.lib.orc_neighbor_count
+        f.argtypes = [C.c_void_p, C.c_uint32]
+        return int(f(self.h, int(vertex)))
+
     def exact_l2(self, query, ids):
         ids = _c(ids, np.uint32)
         out = np.zeros(len(ids), np.float32)

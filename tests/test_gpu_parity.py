@@ -40,6 +40,18 @@ def test_search_batch_matches_reference(cph, gold, name, bits, variant):
         assert ids.dtype == np.int64 and d.dtype == np.float32 and ids.shape == (len(Q), k)
         assert np.array_equal(ids, gold[f"S/{name}/b{bits}/{variant}/k{k}/ids"]), (name, bits, variant, k)
         assert _beq(d, gold[f"S/{name}/b{bits}/{variant}/k{k}/d"]), (name, bits, variant, k)
+    # The 24 queries above took the small-batch launch (full-capacity slots, the instantiation that fetches whole blocks).
+    # Explicit search parameters keep the general path: 8 slots and a queue, the launch order, and for 4-bit codes at
+    # D = 128 the probe-first instantiation followed by the re-run launch -- `bignop` makes every third vertex' stage-1
+    # bounds fail, so queries whose stage-2 decision needs the unfetched codes are handed over there.
+    ix.set_search_params(slots=8, beam_capacity=0)
+    for k in (10, 100):
+        ids, d = ix.search_batch(Q, k)
+        assert np.array_equal(ids, gold[f"S/{name}/b{bits}/{variant}/k{k}/ids"]), (name, bits, variant, k, "general path")
+        assert _beq(d, gold[f"S/{name}/b{bits}/{variant}/k{k}/d"]), (name, bits, variant, k, "general path")
+    st = ix.last_search_stats()
+    if variant == "bignop" and bits == 4:
+        print("bignop general path:", st)
 
 
 @pytest.mark.parametrize("name,bits,variant", [c for c in CASES if c[2] in ("plain", "gamma")])
@@ -55,10 +67,13 @@ def test_search_single_unpadded(cph, gold, name, bits, variant):
     assert np.array_equal(ids64, gold[f"S1/{name}/b{bits}/{variant}/q1/ids"])
 
 
-@pytest.mark.parametrize("name,bits", [(n, b) for n, s in DATASETS.items() for b in s["bits"]])
-def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
-    ix = _load(cph, name, bits)
-    oi = oracle.load(fixture_path(name, bits))
+@pytest.mark.parametrize("name,bits,variant", [(n, b, v) for n, s in DATASETS.items() for b in s["bits"]
+                                               for v in ("plain", "shortcount") if v in s["variants"]])
+def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits, variant):
+    """`shortcount`: every third vertex' list is cut to 0 / 5 / 13 / 29 / 31 entries -- the lanes from 8 * (count / 8) on take
+    the reference's scalar tail (different FMA contraction, tests/golden F/../c<count>), the lanes behind count are unused."""
+    ix = _load(cph, name, bits, variant)
+    oi = oracle.load(fixture_path(name, bits, variant))
     Q = gold[f"Q/{name}"]
     rng = np.random.default_rng(5)
     D = DATASETS[name]["D"]
@@ -73,11 +88,17 @@ def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
         for qp_tail, dqp in (((1.0, 0.0, 0.0, 0.1), 37.5), ((0.93, 0.02, 0.55, -0.05), 2.5e3),
                              ((1.0, 0.0, 0.0, 0.0), 0.0), ((1.0, 0.0, 0.0, 0.3), 5e-13)):
             qp = np.array([co[0], co[1], co[2], *qp_tail], np.float32)
-            for v in rng.integers(0, oi.n, 6):
+            verts = list(rng.integers(0, oi.n, 6))
+            if variant == "shortcount":
+                verts += [1, 4, 7, 10, 13]          # counts 0, 5, 13, 29, 31 (golden_util.VARIANTS)
+            for v in verts:
+                cnt = oi.neighbor_count(v)
                 s, m, e, lo, lo1 = ix.fastscan_block(lut, qp, v, dqp)
                 os_, om, oe, olo, olo1 = oi.fastscan_vertex(lut, qp, v, dqp)
-                assert np.array_equal(s, os_) and np.array_equal(m, om), (name, bits, v)
-                assert _beq(e, oe) and _beq(lo, olo) and _beq(lo1, olo1), (name, bits, v, dqp)
+                assert np.array_equal(s[:cnt], os_[:cnt]) and np.array_equal(m[:cnt], om[:cnt]), (name, bits, v)
+                assert _beq(e[:cnt], oe[:cnt]) and _beq(lo[:cnt], olo[:cnt]) and _beq(lo1[:cnt], olo1[:cnt]), (name, bits, v, dqp, cnt)
+                if cnt < 32:
+                    continue
                 if bits > 1:
                     # stage-2 skip: result heap full and a threshold below every stage-1 bound
                     thr = float(np.min(olo1)) * 0.5
@@ -91,9 +112,10 @@ def test_fastscan_block_and_exact_l2(cph, oracle, gold, name, bits):
         qp = np.array([co[0], co[1], co[2], 0.97, 0.01, 0.2, 0.07], np.float32)
         for dqp in rng.uniform(0.01, 3e4, 40).astype(np.float32):
             v = int(rng.integers(0, oi.n))
+            cnt = oi.neighbor_count(v)
             s, m, e, lo, lo1 = ix.fastscan_block(lut, qp, v, float(dqp))
             os_, om, oe, olo, olo1 = oi.fastscan_vertex(lut, qp, v, float(dqp))
-            assert _beq(e, oe) and _beq(lo, olo) and _beq(lo1, olo1), (name, bits, v, dqp)
+            assert _beq(e[:cnt], oe[:cnt]) and _beq(lo[:cnt], olo[:cnt]) and _beq(lo1[:cnt], olo1[:cnt]), (name, bits, v, dqp)
         ids = rng.integers(0, oi.n, 50).astype(np.uint32)
         assert _beq(ix.exact_l2(Q[qi], ids), oi.exact_l2(Q[qi], ids))
 
@@ -253,6 +275,58 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             ids, d = ix.search_batch(Q, k)
             assert np.array_equal(ids, rids), (bits, k)
             assert _beq(d, rd), (bits, k)
+
+
+@pytest.mark.parametrize("patch", [None, dict(search_gamma=1.15, gamma_max=1.6, gamma_beta=0.6, gamma_warmup=5)])
+def test_search_trajectory_counters_at_scale(cph, oracle, tmp_path, patch):
+    """Not only the top-k: the search PATH.  Per-query expansion counts and the batch totals of new neighbours, beam pushes
+    and skipped stage-2 batches against the oracle's counters on a 60,000-vertex 4-bit index, 1,500 queries (~2 M
+    expansions) -- for the probe-first instantiation (the batch path of 4-bit D = 128, which sees only the NEW neighbours'
+    codes and has to reproduce the reference's stage-2 decision over ALL of a list, rabitq_search.hpp:178-187) and for the
+    instantiation without it (the small-batch launch).  With the builder's calibration (gamma ~ 1e9: DABS off) and with a
+    finite gamma patched in (DABS and gamma-termination on)."""
+    from golden_util import apply_patch
+    rng = np.random.default_rng(4242)
+    n, dim, bits, k = 60000, 128, 4, 10
+    X = rng.standard_normal((n, dim)).astype(np.float32)        # unclustered: ~1,000 expansions per query
+    Q = rng.standard_normal((1500, dim)).astype(np.float32)
+    ix = cph.CPIndex(dim, bits)
+    ix.build(X)
+    ix.finalize()
+    p = str(tmp_path / "traj.idx")
+    ix.save(p)
+    if patch:
+        data = open(p, "rb").read()
+        open(p, "wb").write(apply_patch(data, patch))
+        ix = cph.CPIndex(dim, bits)
+        ix.load(p)
+    oi = oracle.load(p)
+    oids, od, _, ctr = oi.search_batch(Q, k, nthreads=16, counters=True)
+    # -- the batch path: probe first
+    ids, d = ix.search_batch(Q, k)
+    st = ix.last_search_stats()
+    work = ix.last_query_expansions(len(Q))
+    assert np.array_equal(ids, oids) and _beq(d, od)
+    assert np.array_equal(work.astype(np.uint64), ctr[:, 0]), int((work != ctr[:, 0]).sum())
+    assert st["expansions"] == int(ctr[:, 0].sum())
+    assert st["new_neighbours"] == int(ctr[:, 3].sum())
+    assert st["beam_pushes"] == int(ctr[:, 4].sum()) - len(Q)          # (the oracle counts the entry's push)
+    assert st["exact_l2"] >= int(ctr[:, 1].sum())                       # speculative reranks: a superset
+    skipped = int(ctr[:, 6].sum())
+    assert st["stage2_skipped"] <= skipped <= st["stage2_skipped"] + st["stage2_undecided"], (st, skipped)
+    print("trajectory:", {"patch": bool(patch), **st, "oracle_stage2_skipped": skipped})
+    # -- the small-batch launch: the instantiation without probe first decides every batch
+    tot = dict(expansions=0, new_neighbours=0, beam_pushes=0, stage2_skipped=0, stage2_undecided=0, stage2_reruns=0)
+    for lo in range(0, 320, 32):
+        ids2, d2 = ix.search_batch(Q[lo:lo + 32], k)
+        st2 = ix.last_search_stats()
+        assert np.array_equal(ids2, oids[lo:lo + 32]) and _beq(d2, od[lo:lo + 32])
+        assert np.array_equal(ix.last_query_expansions(32).astype(np.uint64), ctr[lo:lo + 32, 0])
+        for key in tot:
+            tot[key] += st2[key]
+    assert tot["expansions"] == int(ctr[:320, 0].sum()) and tot["new_neighbours"] == int(ctr[:320, 3].sum())
+    assert tot["beam_pushes"] == int(ctr[:320, 4].sum()) - 320
+    assert tot["stage2_skipped"] == int(ctr[:320, 6].sum()) and tot["stage2_undecided"] == 0 and tot["stage2_reruns"] == 0
 
 
 @pytest.mark.parametrize("n_fill", [1, 2, 3, 7, 254, 255, 256, 257, 300, 511, 512, 4095, 4096, 4097, 8191, 8192, 9000, 16384, 70000, 262143, 262144, 270000])

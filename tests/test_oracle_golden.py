@@ -6,7 +6,7 @@ encoder and the full search results (ids AND distances, duplicates and ties incl
 import numpy as np
 import pytest
 
-from golden_util import DATASETS, KS, fixture_path
+from golden_util import DATASETS, KS, SHORT_COUNTS, fixture_path
 
 
 def _beq(a, b):
@@ -53,6 +53,17 @@ def test_fastscan_block(oracle, gold, D, bits):
                 assert _beq(e, gold[f"{k}/est"][a, c, i])
                 assert _beq(lo, gold[f"{k}/lower"][a, c, i])
                 assert _beq(lo1, gold[f"{k}/lower1"][a, c, i])
+                # short neighbour lists: the scalar tails for count % 8 != 0 (fastscan_kernel.hpp:174-193, :324-345)
+                for cnt in SHORT_COUNTS:
+                    if bits == 1:
+                        e, lo = oracle.convert_1bit(D, qp, s, nop[i], ipqo[i], ipcp[i], pop[i], dqp, cnt)
+                        lo1 = lo
+                    else:
+                        lo1 = oracle.convert_msb(D, bits, qp, m2, nop[i], ipqo[i], ipcp[i], pop[i], dqp, cnt)
+                        e, lo = oracle.convert_nbit(D, bits, qp, s, m, nop[i], ipqo[i], ipcp[i],
+                                                    pop[i], wpop[i], dqp, cnt)
+                    for got, name in ((e, "est"), (lo, "lower"), (lo1, "lower1")):
+                        assert _beq(got[:cnt], gold[f"{k}/c{cnt}/{name}"][a, c, i, :cnt]), (D, bits, cnt, name)
 
 
 @pytest.mark.parametrize("D", [16, 128, 1024])
