@@ -1001,11 +1001,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     float lo1 = 0.0f, lo2 = 0.0f;
                     if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2, tl);
                     // any_survivor (:178-187) ranges over ALL the list's neighbours, estimated before or not
-#ifdef CPH_AB_NOEXPECT
-                    if (nn_sz < k || __any(fetched && valid && lo1 < worst0)) {
-#else
                     if (__builtin_expect(nn_sz < k || __any(fetched && valid && lo1 < worst0), 1)) {
-#endif
                         est = stage2_est_only<BW>(qp, v, dqp, tl);
                         lower = lo2;
                     } else if constexpr (!kProbeFirst) {            // the reference's skipped batch (:201-205)
@@ -1025,7 +1021,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                         // decision on the real bounds.  (The stage-1 bounds are loose -- the reference itself never
                         // skips a batch on its own graphs, SURVEY F4 -- so neither happens outside the fixtures that
                         // force it: 0 of 2.65 M expansions on the C2 benchmark.)
-                        est = stage2_est_only<BW>(qp, v, dqp, tl);
+                        // (The estimate is computed from a laundered copy of the sum: left recognisable, the compiler
+                        // merges this call with the one of the usual branch and hoists both above the ballot, which
+                        // measured 15 % slower on the C2 benchmark -- the estimate's division chain then sits in front
+                        // of the branch every expansion waits on.)
+                        LaneEst w = v;
+                        asm volatile("" : "+v"(w.nbit));
+                        est = stage2_est_only<BW>(qp, w, dqp, tl);
                         lower = lo2;
                         const bool acts = fetched && !(lo2 >= worst0) && (est < worst0 || est < gamma_q * worst0);
                         if (__any(acts)) return false;
@@ -1281,7 +1283,9 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             atomicAdd(&stats[1], (unsigned long long)st_exact);
             atomicAdd(&stats[2], (unsigned long long)st_new);
             atomicAdd(&stats[3], (unsigned long long)st_push);
-            atomicAdd(&stats[4], (unsigned long long)st_skip);
+            // (guarded: an instantiation that can never skip would add a constant zero, which the compiler turns into an
+            // atomic LOAD of this contended line -- a synchronous round trip per query that cost the probe-first kernel 15 %)
+            if (st_skip) atomicAdd(&stats[4], (unsigned long long)st_skip);
             atomicAdd(&stats[7], (unsigned long long)st_allseen);
 #if !defined(CPH_PHASE_TIMERS) && !defined(CPH_TRAFFIC_STATS)
             if (stage2_redo) atomicAdd(&stats[8], 1ull);          // queries handed to the re-run launch for a stage-2 decision
