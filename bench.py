@@ -2,7 +2,9 @@
 """bench.py — headline benchmark of the MI355X-native CP-HNSW hot path.
 
     python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5|recall]
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+     ..., WORLD_SIZE must equal --gpus -- or on its own: bench.py then starts the N ranks itself, before it touches the
+     GPU, and relays rank 0's line)
 
 Default workload = BASELINE.json configs[1] (c2): SIFT1M-class synthetic data, 1M x 128 (D=128),
 4-bit RaBitQ codes, R=32, index built in-bench by this repo's GPU builder, k=10 (the reference's
@@ -435,9 +437,13 @@ def make_step(search_device, q_shard, k, packs, streams, use_dist, stream_ctx):
     return step
 
 
+LAST_LOCAL_ELAPSED = None      # this rank's own elapsed time of the last timed_region (before the MAX over ranks)
+
+
 def timed_region(step, steps, warmup, serial, use_dist, dist, sync, dev, marks_log=None, prime=4):
     """The contract's timed region: two untimed priming passes (allocator pools, RCCL's per-stream state), W warm-up
     steps, barrier + synchronize, EXACTLY `steps` steps, synchronize + barrier, MAX of the elapsed time over ranks."""
+    global LAST_LOCAL_ELAPSED
     for i in range(prime):
         step(i, serial)
     sync()
@@ -454,6 +460,7 @@ def timed_region(step, steps, warmup, serial, use_dist, dist, sync, dev, marks_l
         if marks_log is not None:
             marks.append(time.perf_counter() - t0)
     sync()
+    LAST_LOCAL_ELAPSED = time.perf_counter() - t0
     if marks_log is not None:
         marks_log("[bench] host time at the end of each step's enqueue (ms): " + " ".join(f"{1e3 * m:.2f}" for m in marks)
                   + f" | drained {1e3 * (time.perf_counter() - t0):.2f}")
@@ -535,6 +542,90 @@ def bench_stream_c5(args, local, world, rank, use_dist, dist, dev):
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks_if_asked(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: THIS process -- which has not touched torch, HIP or
+    the GPU yet -- starts the N ranks as a fresh child (`python -m torch.distributed.run`, one process per GPU, rendezvous
+    on 127.0.0.1), lets rank 0's JSON line through on the inherited stdout and exits with the child's code.  Under a
+    launcher (WORLD_SIZE set) the two must agree."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks; "
+                             "pass the same number to both")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {args.gpus}: starting the ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def per_rank_qps(dist, use_dist, dev, queries, steps):
+    """Every rank's own rate over the timed region (its elapsed time before the MAX): min / max over ranks."""
+    import torch
+    mine = queries * steps / LAST_LOCAL_ELAPSED
+    if not use_dist:
+        return {"min": mine, "max": mine}
+    t = torch.tensor([mine], device=dev, dtype=torch.float64)
+    allv = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, t)
+    v = [float(x.item()) for x in allv]
+    return {"min": min(v), "max": max(v)}
+
+
+def stub_main(args):
+    """TEST HOOK (tests/test_dist_sharding.py): the N > 1 entry of this file -- launcher, rank environment, sharding, step
+    rotation, the packed gather inside the step, barrier-bracketed timed region, MAX over ranks, rank 0's line -- on CPU
+    tensors over gloo, with a stand-in for the search (a deterministic function of the query rows).  Not a fallback of
+    the product: the line says `stub` and carries no performance claim."""
+    import torch
+    import torch.distributed as dist
+    from cphnsw_mi355x.dist import PackedResults
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    use_dist = world > 1
+    if use_dist:
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    nq, k, dim = args.nq_per_gpu or 48, 10, 16
+    Q = np.random.default_rng(7).standard_normal((nq * world, dim)).astype(np.float32)
+    q_shard = torch.from_numpy(Q[rank * nq:(rank + 1) * nq])
+
+    def stub_search(qs, kk, out, stream):
+        key = (qs.abs().sum(dim=1) * 1000.0).to(torch.int64)
+        out[0].copy_(key[:, None] + torch.arange(kk)[None, :])
+        out[1].copy_(qs[:, :1].abs().expand(-1, kk) + torch.arange(kk, dtype=torch.float32)[None, :])
+        return out
+    packs = [PackedResults(nq, k, world, dev) for _ in range(2)]
+    step = make_step(stub_search, q_shard, k, packs, ["s0", "s1"], use_dist, lambda st: NullStream())
+    el, _, _ = timed_region(step, args.steps, args.warmup, False, use_dist, dist, lambda: None, dev)
+    rates = per_rank_qps(dist, use_dist, dev, nq, args.steps)
+    last = packs[(args.steps - 1) % 2]
+    if use_dist:
+        whole = last.all
+    else:
+        whole = last.buf[None, :]
+    ids = whole[:, : nq * k * 8].contiguous().view(torch.int64).view(world * nq, k)
+    if rank == 0:
+        print(json.dumps({"metric": "stub (control flow only)", "stub": True, "value": nq * world * args.steps / el,
+                          "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": el / args.steps * 1e3, "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                          "backend": "gloo", "per_rank_qps": rates, "ids_checksum": int(ids.sum().item()),
+                          "rows": int(ids.shape[0])}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -559,7 +650,11 @@ def main():
                          "untimed trial of 2 and 4 picks the faster")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("CPH_BENCH_SLOTS", 0)), help="resident query slots per batch (0 = automatic)")
     ap.add_argument("--workdir", default=os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench"))
+    ap.add_argument("--stub-search", action="store_true", help=argparse.SUPPRESS)   # test hook: stub_main
     args = ap.parse_args()
+    spawn_ranks_if_asked(args)      # N > 1 without a launcher: start the ranks and relay (never returns then)
+    if args.stub_search:
+        return stub_main(args)
 
     global AFFINITY0
     AFFINITY0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None   # before any OpenMP runtime binds this thread
@@ -667,6 +762,7 @@ def main():
     log(f"[bench] rank {rank}: timed region, k={k_run}")
     elapsed, ids, d = timed(args.steps, args.serial)
     qps = nq_total * args.steps / elapsed
+    rank_rates = per_rank_qps(dist, use_dist, dev, nq_gpu, args.steps)
     log(f"[bench] rank {rank}: {qps:.0f} q/s")
 
     # ---- the same kernel with a full queue (rank 0, c2 / c4): one launch over ten batches' worth of DISTINCT queries.  The
@@ -740,6 +836,8 @@ def main():
             "value": qps,
             "unit": "queries/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if use_dist else 1,
+            "per_rank_qps": rank_rates,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -6,8 +6,12 @@
 // fails with CPH_RUNTIME_ERROR.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -123,10 +127,25 @@ struct BatchSet {
     uint32_t nq = 0;          // size of that batch
     uint32_t run_slots = 0;   // slots its search launch used
     uint64_t run_cap = 0;     // per-slot capacity that launch ran with (n + 1 on the full-capacity slots of the small-batch path)
+    bool stats_in_hbm = false; // the last batch's statistics were not copied to pin_stats yet
 };
 constexpr int kStatWords = 18;
 constexpr int kMaxBatchSets = 4;
+constexpr int kLeaderSlots = 4;             // launches of coalesced cph_search callers that may be in flight together
+constexpr uint64_t kLeaderGroup = 16;       // callers per such launch at most
 constexpr uint64_t kSmallBatch = 32;        // batches up to this size take the copy-free path of cph_search / cph_search_batch
+
+// One caller of cph_search waiting for its answer (see coalesced_search).
+struct SearchReq {
+    const float* query;
+    uint64_t k;            // already clamped to >= 1
+    int64_t* ids;
+    float* dist;
+    uint64_t* m;
+    int rc = CPH_OK;
+    std::string err;
+    bool done = false;
+};
 
 struct cph_index {
     uint64_t dim = 0;
@@ -158,7 +177,8 @@ struct cph_index {
     NativeMapping native_map;
     const uint8_t* own_view = nullptr;
     std::vector<uint8_t> own_store;    // own-code headers of an index built here (own_view points into it)
-    BatchSet sets[kMaxBatchSets];
+    // [0, kMaxBatchSets): the sets batches rotate over; behind them one private set per leader slot of cph_search
+    BatchSet sets[kMaxBatchSets + kLeaderSlots];
     int n_sets = 2;                    // sets in rotation (cph_set_batch_sets): batches that may be in flight together
     int last_set = kMaxBatchSets - 1;  // the set handed out last (they take turns)
     int last_search = -1;              // the set the most recent search went to
@@ -170,6 +190,26 @@ struct cph_index {
     uint64_t auto_cap = 0;             // grown when a batch had to re-run queries
     bool pf_off = false;               // probe first switched off: a batch sent > 2 % of its queries to the re-run launch for a stage-2 decision
     std::mutex mu;
+    // concurrent cph_search callers (the reference: shared lock, T threads search in parallel, api/hnsw_index.hpp:172):
+    // whoever finds no launch in flight leads one for everybody queued so far
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<SearchReq*> waiting;
+    // a leader slot = a stream, a pinned device-mapped I/O buffer and a batch set (sets[kMaxBatchSets + i]) of its own
+    struct LeaderSlot {
+        bool busy = false;
+        hipStream_t stream = nullptr;
+        uint8_t* pin = nullptr;
+        uint8_t* pin_dev = nullptr;
+        size_t pin_bytes = 0;
+        size_t last_group = 0;     // callers its previous launch answered
+    } leaders[kLeaderSlots];
+    int gathering = 0;             // leaders holding their launch back for callers that are about to come back
+    // Measured on C2 with 16 / 32 caller threads (profiles/r4_concurrent_search.md): 3 slots and a 150-us gathering window
+    // -- few, large launches: one launch answers 1 or 16 callers in nearly the same time (it lasts as long as its
+    // longest query), while more than three small launches in flight slow each other down.
+    int n_leaders = 3;             // slots in use (CPH_LEADER_SLOTS, at most kLeaderSlots)
+    int gather_us = 150;           // CPH_GATHER_US
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
 };
@@ -333,19 +373,22 @@ void materialize_search_data(cph_index* h) {
 
 // Picks the set for the next batch (the two alternate) and makes `st` wait for the batch that
 // used it before.  If that batch had to re-run queries, later batches get a larger capacity.
+void init_set(BatchSet& s) {
+    if (s.ev0) return;
+    HIP_CHECK(hipEventCreate(&s.ev0));
+    HIP_CHECK(hipEventCreate(&s.ev1));
+    HIP_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.pin_stats), kStatWords * 8, hipHostMallocDefault));
+    std::memset(s.pin_stats, 0, kStatWords * 8);
+}
+
 BatchSet& next_set(cph_index* h, hipStream_t st) {
     h->last_set = (h->last_set + 1) % h->n_sets;
     BatchSet& s = h->sets[h->last_set];
-    if (!s.ev0) {
-        HIP_CHECK(hipEventCreate(&s.ev0));
-        HIP_CHECK(hipEventCreate(&s.ev1));
-        HIP_CHECK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s.pin_stats), kStatWords * 8, hipHostMallocDefault));
-        std::memset(s.pin_stats, 0, kStatWords * 8);
-    }
+    init_set(s);
     // (either set's finished batch counts: the other set's is the more recent one)
     for (BatchSet& o : h->sets) {
-        if (!(o.used && o.ev_done && hipEventQuery(o.ev_done) == hipSuccess)) continue;
+        if (!(o.used && o.ev_done && !o.stats_in_hbm && hipEventQuery(o.ev_done) == hipSuccess)) continue;
         // [5] = queries re-run, [8] = those of them that were re-run for a stage-2 decision (probe first), not for capacity
         if (o.pin_stats[5] > o.pin_stats[8] && o.cap < h->host.n + 1)
             h->auto_cap = std::max<uint64_t>(h->auto_cap, std::min<uint64_t>(h->host.n + 1, o.cap * 4));
@@ -423,7 +466,9 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const uint64_t per = (n + 1) * 4 + ((uint64_t)kBeamPagesDwords + beam_tail_dwords(n + 1)) * 4 + bm_words * 4;
-        const uint32_t rs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (uint64_t)(free_b * 0.25) / per));
+        // (a leader slot's private set answers at most kLeaderGroup callers per launch)
+        const uint64_t want = (&s - h->sets) >= kMaxBatchSets ? kLeaderGroup : kSmallBatch;
+        const uint32_t rs = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)(free_b * 0.25) / per));
         s.r_bitmaps.alloc((size_t)rs * bm_words);
         HIP_CHECK(hipMemsetAsync(s.r_bitmaps.p, 0, (size_t)rs * bm_words * 4, st));
         s.r_logids.alloc((size_t)rs * (n + 1));
@@ -575,8 +620,11 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         if (rerun) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st);
     }
     HIP_CHECK(hipEventRecord(s.ev1, st));
-    // the statistics block lands in pinned host memory; it is only read when somebody asks
-    HIP_CHECK(hipMemcpyAsync(s.pin_stats, s.d_stats.p, kStatWords * 8, hipMemcpyDeviceToHost, st));
+    // the statistics block lands in pinned host memory; it is only read when somebody asks.  (The private sets of the
+    // cph_search leader slots leave it in HBM until then: their callers wait for the stream, and the copy command would
+    // sit on that path -- nothing of theirs can overflow, so nobody reads the block unasked.)
+    s.stats_in_hbm = (&s - h->sets) >= kMaxBatchSets;
+    if (!s.stats_in_hbm) HIP_CHECK(hipMemcpyAsync(s.pin_stats, s.d_stats.p, kStatWords * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(s.ev_done, st));
     s.used = true;
     h->last_search = (int)(&s - h->sets);
@@ -615,6 +663,16 @@ SmallIo small_io(cph_index* h, BatchSet& s, uint64_t n, uint64_t k) {
 }
 
 }  // namespace
+
+// diagnostic build (-DCPH_SEARCH_TRACE): where a coalesced cph_search launch spends its host time
+#ifdef CPH_SEARCH_TRACE
+static std::atomic<uint64_t> g_tr[6];   // groups, callers, ns waiting for the handle mutex, ns enqueuing, ns waiting for the device, ns copying out
+static inline uint64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CPH_TR(i, v) g_tr[i] += (v)
+#else
+#define CPH_TR(i, v) do {} while (0)
+static inline uint64_t now_ns() { return 0; }
+#endif
 
 // ---------------------------------------------------------------------------------------
 extern "C" {
@@ -655,6 +713,8 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
+        if (const char* e = getenv("CPH_LEADER_SLOTS")) h->n_leaders = std::max(1, std::min(kLeaderSlots, atoi(e)));
+        if (const char* e = getenv("CPH_GATHER_US")) h->gather_us = std::max(0, atoi(e));
         if (const char* e = getenv("CPH_WAVES_PER_CU")) { h->waves_per_cu = (uint32_t)std::max(1, atoi(e)); h->waves_from_env = true; }
         *out = h;
     });
@@ -672,7 +732,16 @@ int cph_destroy(cph_index* h) {
             if (s.pin_stats) (void)hipHostFree(s.pin_stats);
             if (s.pin_io) (void)hipHostFree(s.pin_io);
         }
+#ifdef CPH_SEARCH_TRACE
+        if (g_tr[0]) fprintf(stderr, "[search trace] groups=%llu callers=%llu per group: mutex wait %.1f us, enqueue %.1f us, device wait %.1f us, copy out %.1f us\n",
+                             (unsigned long long)g_tr[0], (unsigned long long)g_tr[1], g_tr[2] / 1e3 / g_tr[0], g_tr[3] / 1e3 / g_tr[0], g_tr[4] / 1e3 / g_tr[0], g_tr[5] / 1e3 / g_tr[0]);
+        for (auto& x : g_tr) x = 0;
+#endif
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+        for (auto& ls : h->leaders) {
+            if (ls.stream) { (void)hipStreamSynchronize(ls.stream); (void)hipStreamDestroy(ls.stream); }
+            if (ls.pin) (void)hipHostFree(ls.pin);
+        }
         delete h;
     });
 }
@@ -1052,6 +1121,10 @@ int cph_last_search_stats(cph_index* h, uint64_t out[12]) {
         BatchSet& s = h->sets[h->last_search];
         h->use_device();
         HIP_CHECK(hipEventSynchronize(s.ev_done));
+        if (s.stats_in_hbm) {
+            HIP_CHECK(hipMemcpy(s.pin_stats, s.d_stats.p, kStatWords * 8, hipMemcpyDeviceToHost));
+            s.stats_in_hbm = false;
+        }
         float ms = 0.0f;
         HIP_CHECK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
         for (int i = 0; i < 6; ++i) out[i] = s.pin_stats[i];
@@ -1174,28 +1247,123 @@ int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, ui
     });
 }
 
+// One launch for up to kSmallBatch single-query callers with the same k: queries gathered into the leader slot's
+// pinned, device-mapped buffer, the copy-free small-batch path on the slot's own stream, every caller's own (unpadded)
+// result copied out.  The handle mutex is held while the launch is ENQUEUED, not while it runs: the next leader's
+// launch (other slot, other stream, the next batch set) overlaps this one.
+static void run_search_group(cph_index* h, cph_index::LeaderSlot& ls, const std::vector<SearchReq*>& group) {
+    const uint64_t n = group.size(), kk = group[0]->k;
+    const uint64_t t0 = now_ns();
+    uint64_t t1 = 0, t2 = 0;
+    const size_t o_dist = n * kk * 8, o_cnt = o_dist + n * kk * 4, o_q = (o_cnt + n * 4 + 15) & ~(size_t)15;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        t1 = now_ns();
+        require_finalized(h);
+        h->use_device();
+        if (!ls.stream) HIP_CHECK(hipStreamCreateWithFlags(&ls.stream, hipStreamNonBlocking));
+        const size_t need = o_q + n * h->dim * 4;
+        if (ls.pin_bytes < need) {          // (the slot is ours alone: nothing in flight reads the old buffer)
+            if (ls.pin) HIP_CHECK(hipHostFree(ls.pin));
+            ls.pin = nullptr; ls.pin_bytes = 0;
+            const size_t bytes = std::max<size_t>(need * 2, 64 * 1024);
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ls.pin), bytes, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ls.pin_dev), ls.pin, 0));
+            ls.pin_bytes = bytes;
+        }
+        float* h_query = reinterpret_cast<float*>(ls.pin + o_q);
+        for (uint64_t i = 0; i < n; ++i) std::memcpy(h_query + i * h->dim, group[i]->query, h->dim * sizeof(float));
+        BatchSet& s = h->sets[kMaxBatchSets + (&ls - h->leaders)];     // the slot's own set: its launches are ordered by its stream
+        init_set(s);
+        stage_queries(h, s, reinterpret_cast<const float*>(ls.pin_dev + o_q), n, ls.stream);      // the encoder reads the queries over PCIe
+        enqueue_search(h, s, (uint32_t)n, (uint32_t)kk, reinterpret_cast<int64_t*>(ls.pin_dev), reinterpret_cast<float*>(ls.pin_dev + o_dist),
+                       ls.stream, reinterpret_cast<uint32_t*>(ls.pin_dev + o_cnt));                 // ... the search writes the results back
+        t2 = now_ns();
+    }
+    HIP_CHECK(hipSetDevice(h->device));
+    HIP_CHECK(hipStreamSynchronize(ls.stream));
+    const uint64_t t3 = now_ns();
+    const int64_t* h_ids = reinterpret_cast<const int64_t*>(ls.pin);
+    const float* h_dist = reinterpret_cast<const float*>(ls.pin + o_dist);
+    const uint32_t* h_count = reinterpret_cast<const uint32_t*>(ls.pin + o_cnt);
+    for (uint64_t i = 0; i < n; ++i) {
+        // the reference returns every result it found (<= max(k,1)); the caller's buffers hold max(k,1) entries
+        const uint32_t cnt = h_count[i];
+        std::memcpy(group[i]->ids, h_ids + i * kk, (size_t)cnt * 8);
+        std::memcpy(group[i]->dist, h_dist + i * kk, (size_t)cnt * 4);
+        *group[i]->m = cnt;
+    }
+    CPH_TR(0, 1); CPH_TR(1, n); CPH_TR(2, t1 - t0); CPH_TR(3, t2 - t1); CPH_TR(4, t3 - t2); CPH_TR(5, now_ns() - t3);
+}
+
+// Concurrent callers of cph_search on one handle.  The reference answers them in parallel under a shared lock
+// (src/bindings.cpp:146-175, api/hnsw_index.hpp:172); a GPU answers them best TOGETHER: a caller that finds a free
+// leader slot takes everybody who queued up so far (same k, at most kLeaderGroup) into one launch; callers arriving
+// while every slot is in flight wait on the condition variable and are gathered by the next leader.  No spinning
+// kernel, no extra thread; a lone caller pays one uncontended mutex more than before.
+static void coalesced_search(cph_index* h, SearchReq& r) {
+    std::unique_lock<std::mutex> lk(h->qmu);
+    h->waiting.push_back(&r);
+    if (h->gathering) h->qcv.notify_all();
+    while (!r.done) {
+        int slot = -1;
+        for (int i = 0; i < h->n_leaders; ++i) if (!h->leaders[i].busy) { slot = i; break; }
+        // (our request may already ride in another leader's launch: then there is nothing to lead)
+        const bool queued = std::find(h->waiting.begin(), h->waiting.end(), &r) != h->waiting.end();
+        if (slot < 0 || !queued) {
+            h->qcv.wait(lk);
+            continue;
+        }
+        h->leaders[slot].busy = true;
+        // Callers that block on their answers come back together: if this slot's previous launch answered several, hold
+        // the launch for up to gather_us while the queue fills to that size (a lone caller never waits).
+        if (h->leaders[slot].last_group > 1 && h->waiting.size() < h->leaders[slot].last_group) {
+            const size_t want = std::min<size_t>(h->leaders[slot].last_group, kLeaderGroup);
+            ++h->gathering;
+            h->qcv.wait_for(lk, std::chrono::microseconds(h->gather_us), [&] { return h->waiting.size() >= want; });
+            --h->gathering;
+            // (the mutex was released meanwhile: another leader may have taken this caller along)
+            if (std::find(h->waiting.begin(), h->waiting.end(), &r) == h->waiting.end()) {
+                h->leaders[slot].busy = false;
+                h->qcv.notify_all();
+                continue;
+            }
+        }
+        std::vector<SearchReq*> group;
+        const uint64_t kk = r.k;
+        const uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(kLeaderGroup, (1u << 20) / kk));
+        for (auto it = h->waiting.begin(); it != h->waiting.end() && group.size() < cap;) {
+            if ((*it)->k == kk) { group.push_back(*it); it = h->waiting.erase(it); } else ++it;
+        }
+        lk.unlock();
+        int rc = CPH_OK;
+        std::string err;
+        try {
+            run_search_group(h, h->leaders[slot], group);
+        } catch (const std::invalid_argument& e) { rc = CPH_INVALID_ARGUMENT; err = e.what();
+        } catch (const std::bad_alloc&) { rc = CPH_OUT_OF_MEMORY; err = "out of memory";
+        } catch (const std::exception& e) { rc = CPH_RUNTIME_ERROR; err = e.what(); }
+        lk.lock();
+        for (SearchReq* g : group) { g->rc = rc; g->err = err; g->done = true; }
+        h->leaders[slot].last_group = group.size();
+        h->leaders[slot].busy = false;
+        h->qcv.notify_all();
+    }
+}
+
 int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
                uint64_t* m) {
-    return guarded([&] {
+    SearchReq r{};
+    const int rc = guarded([&] {
         if (!h) throw InvalidArg("null handle");
-        std::lock_guard<std::mutex> lk(h->mu);
-        require_finalized(h);
+        if (!query || !ids || !dist || !m) throw InvalidArg("null argument");
         const uint64_t kk = std::max<uint64_t>(k, 1);  // api/hnsw_index.hpp:187
         if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
-        h->use_device();
-        hipStream_t st = own_stream(h);
-        BatchSet& s = next_set(h, st);
-        SmallIo io = small_io(h, s, 1, kk);
-        std::memcpy(io.h_query, query, h->dim * sizeof(float));
-        stage_queries(h, s, io.d_query, 1, st);                       // the encoder reads the query over PCIe
-        enqueue_search(h, s, 1, (uint32_t)kk, io.d_ids, io.d_dist, st, io.d_count);   // ... the search writes the results back
-        HIP_CHECK(hipStreamSynchronize(st));
-        // the reference returns every result it found (<= max(k,1)); the caller's buffers hold max(k,1) entries
-        const uint32_t cnt = io.h_count[0];
-        std::memcpy(ids, io.h_ids, (size_t)cnt * 8);
-        std::memcpy(dist, io.h_dist, (size_t)cnt * 4);
-        *m = cnt;
+        r.query = query; r.k = kk; r.ids = ids; r.dist = dist; r.m = m;
+        coalesced_search(h, r);
     });
+    if (rc != CPH_OK) return rc;
+    return r.rc == CPH_OK ? CPH_OK : fail(r.rc, r.err);
 }
 
 // ---- hooks ---------------------------------------------------------------------------

@@ -241,3 +241,30 @@ def test_rccl_gather_of_hip_search_matches_goldens(gold):
     for a, b in ((ids, d), (gi, gd), (pi, pd)):
         assert np.array_equal(a, gold["S/g128/b4/plain/k10/ids"])
         assert b.tobytes() == gold["S/g128/b4/plain/k10/d"].tobytes()
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must become a 2-rank run by itself (the parent starts
+    `python -m torch.distributed.run` before it touches torch / the GPU and relays rank 0's line).  Driven here through
+    bench.py's test hook: CPU tensors over gloo, a stand-in for the search, the real launcher / sharding / step / gather /
+    timed-region code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--stub-search"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["stub"] is True
+    assert j["rows"] == 96                    # two shards of 48 queries, gathered rank-major inside the step
+    # the gathered ids are what one process computes for the whole batch
+    Q = np.random.default_rng(7).standard_normal((96, 16)).astype(np.float32)
+    key = (np.abs(Q).sum(axis=1, dtype=np.float32) * np.float32(1000.0)).astype(np.int64)
+    assert j["ids_checksum"] == int((key[:, None] + np.arange(10)[None, :]).sum())
+    assert j["per_rank_qps"]["min"] <= j["per_rank_qps"]["max"] and j["value"] <= 2 * j["per_rank_qps"]["max"] * 1.001
+    # a launcher that disagrees with --gpus is an error, not a silently mislabelled run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-search"],
+                       capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="3"))
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

@@ -610,3 +610,84 @@ def test_torch_can_initialise_after_the_library():
             "x = torch.ones(8, device='cuda').sum().item(); assert x == 8.0; print('OK')") % os.path.join(root, "rabitq-ann-search_amd")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def _threaded_search(ix, Q, k, n_threads, calls):
+    """n_threads Python threads, each calling ix.search() `calls` times (ctypes releases the GIL around the C call);
+    returns {(thread, call): (ids, dist)} and the wall time."""
+    import threading
+    import time
+    out, errs = {}, []
+    start = threading.Barrier(n_threads + 1)
+
+    def work(t):
+        try:
+            start.wait()
+            for c in range(calls):
+                qi = (t * calls + c) % len(Q)
+                out[(t, c)] = (qi,) + ix.search(Q[qi], k)
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    el = time.perf_counter() - t0
+    assert not errs, errs[:3]
+    return out, el
+
+
+def test_concurrent_search_calls_are_coalesced_and_exact(cph, gold, tmp_path):
+    """The reference's search() takes a SHARED lock and releases the GIL (src/bindings.cpp:146-175,
+    api/hnsw_index.hpp:172): T threads search one index in parallel.  Here concurrent callers are gathered into one
+    launch by whoever finds none in flight (cph_search: leader / followers).  16 threads x 200 calls on a fixture and
+    on a 70,000-vertex index: every answer equals the batch path's row (unpadded), mixed k included."""
+    ix = _load(cph, "g128", 4)
+    Q = gold["Q/g128"]
+    ref = {k: ix.search_batch(Q, k) for k in (1, 10, 20)}
+    for k in (10, 1):
+        out, _ = _threaded_search(ix, Q, k, 16, 200)
+        assert len(out) == 16 * 200
+        for (_, _), (qi, ids, d) in out.items():
+            m = int((ref[k][0][qi] >= 0).sum())
+            assert np.array_equal(ids, ref[k][0][qi, :m]) and _beq(d, ref[k][1][qi, :m])
+    # mixed k: callers with different k never share a launch
+    import threading
+    res, errs = {}, []
+
+    def work(t):
+        try:
+            k = (1, 10, 20)[t % 3]
+            for c in range(60):
+                qi = (7 * t + c) % len(Q)
+                res[(t, c)] = (k, qi) + ix.search(Q[qi], k)
+        except Exception as e:       # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs[:3]
+    for (k, qi, ids, d) in res.values():
+        m = int((ref[k][0][qi] >= 0).sum())
+        assert np.array_equal(ids, ref[k][0][qi, :m]) and _beq(d, ref[k][1][qi, :m])
+    # an index of some size: the launches are long enough for callers to pile up behind them
+    rng = np.random.default_rng(99)
+    n, dim = 70000, 128
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    Qb = rng.standard_normal((400, dim)).astype(np.float32)
+    big = cph.CPIndex(dim, 4)
+    big.build(X)
+    big.finalize()
+    rids, rd = big.search_batch(Qb, 10)
+    out, el = _threaded_search(big, Qb, 10, 16, 200)
+    for (_, _), (qi, ids, d) in out.items():
+        m = int((rids[qi] >= 0).sum())
+        assert np.array_equal(ids, rids[qi, :m]) and _beq(d, rd[qi, :m])
+    print(f"concurrent search: 16 threads x 200 calls on 70k x 128 / 4-bit: {16 * 200 / el:.0f} QPS")
+    # errors reach every caller of a group: an unfinalized index
+    empty = cph.CPIndex(128, 4)
+    with pytest.raises(RuntimeError):
+        empty.search(np.zeros(128, np.float32), 10)
