@@ -29,9 +29,13 @@ The JSON line also carries
     on the SIFT-like data (our ids are the reference's bit for bit), so a short child run of the `recall1m` config --
     Gaussian data at the same scale, 1M x 128, 2-bit, k = 20, where it is -- is condensed into this object: QPS, recall,
     kernel fraction of HBM peak, the reference's QPS and the bit-level parity check on a bounded query sample,
-  * legs (c2, N = 1): condensed child lines of the BASELINE configs C3 (1M x 960) and C5 (streaming FastScan over the
-    largest block set that fits), each with its parity check; `legs_failed` lists legs that broke (exit code 3 under
-    CPH_BENCH_STRICT=1),
+  * qps_at_recall_gate_4bit (c2, N = 1): the metric as worded -- the same data with 4-bit codes, k = 500 (the first k
+    of profiles/r4_gate_4bit_k_sweep.md that meets the gate),
+  * legs (c2, N = 1): condensed child lines of the BASELINE configs C3 (1M x 960), C5 (streaming FastScan over the
+    largest block set that fits) and -- when the run is younger than --c4-deadline seconds at that point -- C4 (10M x
+    96), each with its parity check; `legs_failed` lists legs that broke, `legs_skipped` the ones not started,
+    `parity_failures` every parity verdict that is false; any of the first or last makes the exit code 3
+    (CPH_BENCH_STRICT=0: line only),
   * fastscan_stream: the streaming FastScan kernel on synthetic neighbour blocks of the config's
     shape (metric part 2: distances/s vs the HBM roofline),
   * roofline: the dominant kernel of the timed region (the persistent search kernel): algorithmic
@@ -295,6 +299,28 @@ def _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle,
                 "queries": int(len(sample_q)), "k": int(K),
                 "ids_identical": bool(np.array_equal(r_ids, g_ids)),
                 "distances_bit_identical": bool(r_d.tobytes() == g_d.tobytes())}
+            # ... and the search PATH, not only its result: per-query expansion counts and the batch totals of new
+            # neighbours and beam pushes against the oracle's counters (the scalar restatement, pinned to the reference
+            # by tests/golden) on the same queries -- the statistics the roofline's algorithmic bytes are computed from
+            st = gpu_index.last_search_stats()
+            work = gpu_index.last_query_expansions(len(sample_q))
+            n_ctr = min(len(sample_q), args.counter_queries)
+            if n_ctr > 0:
+                oi = Oracle().load(path)
+                _, _, _, ctr = oi.search_batch(sample_q[:n_ctr], K, nthreads=cores, counters=True)
+                del oi
+                g2_ids, _ = gpu_index.search_batch(sample_q[:n_ctr], K)
+                st2 = gpu_index.last_search_stats()
+                work2 = gpu_index.last_query_expansions(n_ctr)
+                out["parity_vs_oracle_counters"] = {
+                    "queries": int(n_ctr),
+                    "expansions_per_query_identical": bool(np.array_equal(work2.astype(np.uint64), ctr[:, 0])),
+                    "new_neighbours_equal": bool(st2["new_neighbours"] == int(ctr[:, 3].sum())),
+                    "beam_pushes_equal": bool(st2["beam_pushes"] == int(ctr[:, 4].sum()) - n_ctr),
+                    "stage2_skipped": {"gpu_decided": st2["stage2_skipped"], "gpu_undecided": st2["stage2_undecided"],
+                                       "oracle": int(ctr[:, 6].sum())},
+                    "expansions": int(ctr[:, 0].sum())}
+            del st, work
         del idx
         # streaming FastScan, same blocks and query as the GPU stream leg: all threads and one thread, each timed
         # for at least half a second (the repetition count follows a calibration pass)
@@ -345,22 +371,24 @@ def _cpu_baseline(args, cfg, path, Q, stream, K, gpu_index, info, cores, Oracle,
     return out
 
 
-def pmc_traffic_ratio(config, k):
+def pmc_traffic_ratio(config, k, bits=None):
     """HBM bytes over algorithmic bytes of the search kernel, from the PMC summary committed for this tree
-    (profiles/r3_pmc_search.json, written by scripts/pmc_search.sh + scripts/pmc_summary.py from separate FETCH_SIZE /
-    WRITE_SIZE passes; FETCH_SIZE counts one 64-byte unit per 128-byte line request on gfx950 -- scripts/micro/
-    fetch_calib.hip -- hence the x2).  None when the file does not cover this workload."""
-    p = os.path.join(ROOT, "profiles", "r3_pmc_search.json")
-    try:
-        rec = json.load(open(p))
-    except Exception:
-        return None
-    if rec.get("config") != config or rec.get("k") != k:
-        return None
-    return rec.get("hbm_bytes_over_algorithmic")
+    (profiles/r4_pmc_search_<config>[_b<bits>]_k<k>.json, written by scripts/pmc_search.sh + scripts/pmc_summary.py from
+    separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE counts one 64-byte unit per 128-byte line request on gfx950 --
+    scripts/micro/fetch_calib.hip -- hence the x2).  None when no file covers this workload."""
+    names = [f"r4_pmc_search_{config}_b{bits}_k{k}.json", f"r4_pmc_search_{config}_k{k}.json"]
+    for nm in names:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", nm)))
+        except Exception:
+            continue
+        if rec.get("config") == config and rec.get("k") == k and (bits is None or rec.get("bits", bits) == bits):
+            return rec.get("hbm_bytes_over_algorithmic")
+    return None
 
 
 STEP_TIMES = os.environ.get("CPH_BENCH_STEP_TIMES") == "1"
+T_START = time.time()
 AFFINITY0 = None
 
 
@@ -375,41 +403,105 @@ def child_line(args, extra, timeout):
     return json.loads(lines[-1]), " ".join(["python", "bench.py"] + extra)
 
 
+def _condense_gate(j, cmd):
+    cb = j.get("cpu_baseline", {})
+    return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "k": j["config"]["k"],
+            "bits": j["config"]["bits"],
+            "recall_at_10": j["recall_at_10"], "recall_target_met": j["recall_target_met"],
+            "ms_per_step": j["ms_per_step"], "kernel_frac_of_hbm_peak": j["roofline"]["frac"],
+            "kernel_moved_frac_of_hbm_peak": j["roofline"].get("moved_frac"),
+            "kernel_ms": j["roofline"]["kernel_ms"], "expansions_per_query": j["roofline"]["expansions_per_query"],
+            "index_build_s": j["config"]["index_build_s"],
+            "reference_qps": cb.get("value"), "reference_threads": cb.get("cores"),
+            "parity_vs_reference": cb.get("parity_vs_reference"),
+            "parity_vs_oracle_counters": cb.get("parity_vs_oracle_counters"), "command": cmd}
+
+
 def recall_gate_leg(args):
     """The metric asks for QPS at recall@10 >= 0.95 on a SIFT1M-class index; the reference algorithm does not reach that
     on the SIFT-like C2 data (ids are bit-identical to the reference's, so neither do we), so the default run also times
     the workload on which it does, at the same scale (`recall1m`: Gaussian 1M x 128, 2-bit, k = 20, index built by the
     GPU builder) -- a short child run of this script after the timed region, its line condensed into one object, with
     the bit-level check against the compiled reference on a bounded query sample.  N = 1 only, like the CPU baseline."""
-    j, cmd = child_line(args, ["--config", args.gate_config, "--steps", "3", "--warmup", "1", "--cpu-queries", "200"], 900)
-    cb = j.get("cpu_baseline", {})
-    return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "k": j["config"]["k"],
-            "recall_at_10": j["recall_at_10"], "recall_target_met": j["recall_target_met"],
-            "ms_per_step": j["ms_per_step"], "kernel_frac_of_hbm_peak": j["roofline"]["frac"],
-            "kernel_ms": j["roofline"]["kernel_ms"], "expansions_per_query": j["roofline"]["expansions_per_query"],
-            "index_build_s": j["config"]["index_build_s"],
-            "reference_qps": cb.get("value"), "reference_threads": cb.get("cores"),
-            "parity_vs_reference": cb.get("parity_vs_reference"), "command": cmd}
+    j, cmd = child_line(args, ["--config", args.gate_config, "--steps", "3", "--warmup", "1", "--cpu-queries", "200",
+                               "--counter-queries", "50"], 900)
+    return _condense_gate(j, cmd)
 
 
-def config_legs(args):
+def recall_gate_leg_4bit(args):
+    """The metric AS WORDED -- 4-bit codes: the same Gaussian 1M x 128 data at 4 bits reaches recall@10 >= 0.95 (first 10
+    unique ids of the k returned) from k = 500 on (profiles/r4_gate_4bit_k_sweep.md: 0.84 at k = 20, 0.93 at k = 200)."""
+    j, cmd = child_line(args, ["--config", args.gate_config, "--bits", "4", "--k", str(args.gate4_k), "--steps", "3", "--warmup", "1",
+                               "--cpu-queries", "100", "--counter-queries", "50", "--recall-queries", "500"], 900)
+    return _condense_gate(j, cmd)
+
+
+def config_legs(args, t_start, failed):
     """The remaining BASELINE configs that fit one GPU in minutes, each as a condensed child line: C3 (GIST1M-class,
-    D = 1024: build + timed steps + 1,000 queries against the compiled reference) and C5 (streaming FastScan over the
-    largest D = 1024 / 2-bit block set that fits, 64 blocks against the oracle).  C4 (10M vectors: a 4-minute build)
-    stays a `--config c4` run (profiles/)."""
+    D = 1024: build + timed steps + 1,000 queries against the compiled reference), C5 (streaming FastScan over the
+    largest D = 1024 / 2-bit block set that fits, 64 blocks against the oracle) and -- if the run is younger than
+    --c4-deadline seconds when its turn comes (a 2.5-minute build) -- C4 (Deep10M-class, 10M x 96: 10k-query QPS, kernel
+    fraction, 500 queries against the compiled reference); else `legs_skipped` says so with the elapsed time.  A leg that
+    breaks leaves an `error` object and its name in `failed`; the others still run."""
     out = {}
-    j, cmd = child_line(args, ["--config", "c3", "--steps", "10", "--warmup", "2", "--cpu-queries", "1000", "--recall-queries", "200"], 900)
-    cb = j.get("cpu_baseline", {})
-    out["c3"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                 "roofline": {k: j["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_ms", "pipelined_frac")},
-                 "fastscan_stream_frac": j["fastscan_stream"]["roofline"]["frac"],
-                 "index_build_s": j["config"]["index_build_s"], "reference_qps": cb.get("value"),
-                 "parity_vs_reference": cb.get("parity_vs_reference"), "command": cmd}
-    j, cmd = child_line(args, ["--config", "c5", "--steps", "5", "--warmup", "1"], 600)
-    out["c5"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                 "roofline": {k: j["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_ms")},
-                 "parity_vs_oracle": j["parity_vs_oracle"], "command": cmd}
-    return out
+    try:
+        j, cmd = child_line(args, ["--config", "c3", "--steps", "10", "--warmup", "2", "--cpu-queries", "1000", "--counter-queries", "200",
+                                   "--recall-queries", "200"], 900)
+        cb = j.get("cpu_baseline", {})
+        out["c3"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                     "roofline": {k: j["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_ms", "pipelined_frac")},
+                     "fastscan_stream_frac": j["fastscan_stream"]["roofline"]["frac"],
+                     "index_build_s": j["config"]["index_build_s"], "reference_qps": cb.get("value"),
+                     "parity_vs_reference": cb.get("parity_vs_reference"),
+                     "parity_vs_oracle_counters": cb.get("parity_vs_oracle_counters"), "command": cmd}
+    except Exception as e:
+        out["c3"] = {"error": repr(e)[:500]}
+        failed.append("c3")
+    try:
+        j, cmd = child_line(args, ["--config", "c5", "--steps", "5", "--warmup", "1"], 600)
+        out["c5"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                     "roofline": {k: j["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_ms")},
+                     "parity_vs_oracle": j["parity_vs_oracle"], "command": cmd}
+    except Exception as e:
+        out["c5"] = {"error": repr(e)[:500]}
+        failed.append("c5")
+    skipped = []
+    elapsed = time.time() - t_start
+    if args.c4_deadline > 0 and elapsed < args.c4_deadline:
+        try:
+            j, cmd = child_line(args, ["--config", "c4", "--steps", "10", "--warmup", "2", "--cpu-queries", "500", "--counter-queries", "200",
+                                       "--recall-queries", "200"], 1500)
+            cb = j.get("cpu_baseline", {})
+            out["c4"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                         "roofline": {k: j["roofline"].get(k) for k in ("kernel", "achieved", "frac", "moved_frac", "kernel_ms", "pipelined_frac")},
+                         "full_queue": j["roofline"].get("full_queue"),
+                         "recall_at_10": j["recall_at_10"],
+                         "index_build_s": j["config"]["index_build_s"], "reference_qps": cb.get("value"),
+                         "parity_vs_reference": cb.get("parity_vs_reference"),
+                         "parity_vs_oracle_counters": cb.get("parity_vs_oracle_counters"), "command": cmd,
+                         "started_at_s": round(elapsed, 1)}
+        except Exception as e:
+            out["c4"] = {"error": repr(e)[:500]}
+            failed.append("c4")
+    else:
+        skipped.append({"leg": "c4", "elapsed_s": round(elapsed, 1), "deadline_s": args.c4_deadline,
+                        "run_it_with": "python bench.py --config c4"})
+    return out, skipped
+
+
+def parity_flags(obj):
+    """Every parity verdict inside a (nested) result object: [(path, bool)]."""
+    found = []
+
+    def walk(o, path):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if isinstance(v, bool) and (k.endswith("identical") or k.endswith("_equal")):
+                    found.append((path + "." + k, v))
+                else:
+                    walk(v, path + "." + k)
+    walk(obj, "")
+    return found
 
 
 class NullStream:
@@ -636,13 +728,19 @@ def main():
     ap.add_argument("--nq-per-gpu", type=int, default=0)
     ap.add_argument("--stream-blocks", type=int, default=0)
     ap.add_argument("--cpu-queries", type=int, default=2_000)
+    ap.add_argument("--counter-queries", type=int, default=2_000,
+                    help="queries of the CPU sample whose per-query expansion counts / totals are also checked against the oracle's counters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recall-leg", action="store_true", help="c2 only: skip the short run of the gate workload")
     ap.add_argument("--no-extra-legs", action="store_true", help="c2 only: skip every child leg (gate workload, C3, C5)")
     ap.add_argument("--gate-config", default="recall1m", choices=["recall", "recall1m"])
+    ap.add_argument("--gate4-k", type=int, default=500, help="k of the 4-bit gate leg (profiles/r4_gate_4bit_k_sweep.md)")
+    ap.add_argument("--c4-deadline", type=float, default=float(os.environ.get("CPH_BENCH_C4_DEADLINE", 200)),
+                    help="start the C4 leg (10M vectors: a 2.5-minute build) only if the run is younger than this many seconds; 0 = never")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("CPH_BENCH_CPU_THREADS", 16)),
                     help="OpenMP threads of the CPU baseline (default: the box' CPU share for one GPU)")
     ap.add_argument("--k", type=int, default=0, help="0 = the config's k")
+    ap.add_argument("--bits", type=int, default=0, choices=[0, 1, 2, 4], help="0 = the config's bit width")
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--serial", action="store_true", help="one stream: every step waits for the previous one")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("CPH_BENCH_STREAMS", 0)),
@@ -688,7 +786,9 @@ def main():
     from cphnsw_mi355x.dist import PackedResults
 
     leg_failure = False
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.bits:
+        cfg["bits"] = args.bits
     n = args.n_index or cfg["n"]
     dim, bits = cfg["dim"], cfg["bits"]
     D = 1 << (dim - 1).bit_length()
@@ -769,7 +869,7 @@ def main():
     # config's own batch is as long as its longest query (a chain of dependent expansions); this launch shows the rate the
     # kernel sustains once that tail is amortised -- reported next to `roofline`, never instead of it.
     full_queue = None
-    ratio_fq = pmc_traffic_ratio(args.config, k_run)
+    ratio_fq = pmc_traffic_ratio(args.config, k_run, bits)
     index.set_batch_sets(2)                                   # every resident slot for one batch from here on
     if args.slots:
         index.set_search_params(slots=0, beam_capacity=0)
@@ -788,6 +888,7 @@ def main():
         full_queue = {"queries_per_launch": nq_big, "kernel_ms": b_s * 1e3, "achieved": b_bytes / b_s / 1e9, "unit": "GB/s",
                       "frac": b_bytes / b_s / 1e9 / HBM_PEAK_GBS, "qps": nq_big / b_s,
                       "traffic": (ratio_fq * b_bytes / b_s / 1e9 if ratio_fq else None),
+                      "moved_frac": (ratio_fq * b_bytes / b_s / 1e9 / HBM_PEAK_GBS if ratio_fq else None),
                       "measured": "one launch of 10x the config's batch (distinct queries), HIP events around it, mean of 3"}
         del q_big
 
@@ -813,7 +914,7 @@ def main():
     k_s = float(np.mean(kernel_us)) * 1e-6
     alg_bytes = stats["expansions"] * 32 * bytes_per_dist + stats["exact_l2"] * bytes_per_exact
     achieved = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
-    ratio = pmc_traffic_ratio(args.config, k_run)
+    ratio = pmc_traffic_ratio(args.config, k_run, bits)
     search_traffic = ratio * achieved if ratio else None
     el_serial, _, _ = timed(args.steps, True)
     qps_serial = nq_total * args.steps / el_serial
@@ -874,6 +975,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": search_traffic, "kernel_ms": k_s * 1e3,
+                         # `frac` prices the ALGORITHMIC bytes (every expansion's whole block + vector) over
+                         # the kernel time: a throughput equivalent.  The probe-first kernel does not fetch the codes of
+                         # neighbours it will skip, so it MOVES fewer bytes than that; `moved_frac` = PMC bytes of the
+                         # same tree / kernel time / peak is its actual HBM utilisation.
+                         "moved_frac": (search_traffic / HBM_PEAK_GBS if search_traffic else None),
+                         "traffic_over_algorithmic": ratio,
                          "measured": "kernel alone: steps serialised on one stream, HIP events around the search launches",
                          "pipelined_achieved": alg_bytes * args.steps / elapsed / 1e9,
                          "pipelined_frac": alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
@@ -888,25 +995,28 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, cfg, path, Q, stream, k_run, index)
-        failed = []
+        failed, skipped = [], []
         if args.config == "c2" and world == 1 and not args.no_extra_legs:
             if not args.no_recall_leg and not gate:
-                try:
-                    out["qps_at_recall_gate"] = recall_gate_leg(args)
-                except Exception as e:       # the main line is still printed; the exit code says a leg broke
-                    out["qps_at_recall_gate"] = {"error": repr(e)[:500]}
-                    failed.append("qps_at_recall_gate")
-            try:
-                out["legs"] = config_legs(args)
-            except Exception as e:
-                out["legs"] = {"error": repr(e)[:500]}
-                failed.append("legs")
+                for name, fn in (("qps_at_recall_gate", recall_gate_leg), ("qps_at_recall_gate_4bit", recall_gate_leg_4bit)):
+                    try:
+                        out[name] = fn(args)
+                    except Exception as e:       # the main line is still printed; the exit code says a leg broke
+                        out[name] = {"error": repr(e)[:500]}
+                        failed.append(name)
+            out["legs"], skipped = config_legs(args, T_START, failed)
         out["timed_region_s"] = elapsed
-        out["legs_failed"] = failed          # loud in the line itself; CPH_BENCH_STRICT=1 also turns it into exit code 3
+        out["legs_failed"] = failed
+        out["legs_skipped"] = skipped
+        bad_parity = [p for p, ok in parity_flags(out) if not ok]
+        out["parity_failures"] = bad_parity
+        out["run_s"] = round(time.time() - T_START, 1)
         print(json.dumps(out), flush=True)
-        if failed:
-            log(f"[bench] FAILED legs: {failed}")
-            leg_failure = os.environ.get("CPH_BENCH_STRICT") == "1"
+        # a leg that broke or any parity verdict that is false is an error of the run: loud in the line AND in the exit
+        # code (CPH_BENCH_STRICT=0 keeps the old behaviour: line only)
+        if failed or bad_parity:
+            log(f"[bench] FAILED legs: {failed}; parity failures: {bad_parity}")
+            leg_failure = os.environ.get("CPH_BENCH_STRICT", "1") != "0"
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -501,6 +501,9 @@ struct Counters {
         lb_pruned_pops, gamma_breaks;
 };
 
+// diagnostic (scripts/probe_locality.py): the ids probed by one query, in order, expansion by expansion
+thread_local std::vector<uint32_t>* g_probe_trace = nullptr;   // [vertex expanded | 0x80000000, then its count neighbour ids]*
+
 // search/rabitq_search.hpp:60-277 with the Index::search prologue
 // (api/hnsw_index.hpp:168-211).
 int search_one(const Index& ix, const float* query /*dim*/, size_t k, std::vector<Result>& out,
@@ -608,8 +611,11 @@ int search_one(const Index& ix, const float* query /*dim*/, size_t k, std::vecto
             }
         }
         bool warmup = nn.size() < k;
+        if (g_probe_trace) g_probe_trace->push_back(cur.id | 0x80000000u);
         for (uint32_t i = 0; i < count; ++i) {
             uint32_t nid = ids[i];
+            if (g_probe_trace)   // bit 30: the neighbour's bounds would let it act at its turn if it were new (filter of :246)
+                g_probe_trace->push_back(nid | ((warmup || !(nn.size() >= k && lower[i] >= nn_worst())) ? 0x40000000u : 0u));
             if (ctr) ctr->nbr_seen++;
             if (estimated[nid]) continue;
             estimated[nid] = 1;
@@ -947,6 +953,19 @@ int orc_fastscan_vertex(void* h, const uint8_t* lut, const float* qp7, uint32_t 
         convert_nbit(ix->bw, qp, sums, msb_out, nop, ipqo, ipcp, pop, wpop, bc, dqp, est, lower);
     }
     return 0;
+}
+
+// diagnostic: the probe sequence of one query (see g_probe_trace); returns the number of words, writes at most cap
+long orc_probe_trace(void* h, const float* query, long k, uint32_t* out, long cap) {
+    Index* ix = static_cast<Index*>(h);
+    std::vector<uint32_t> tr;
+    std::vector<Result> res;
+    g_probe_trace = &tr;
+    search_one(*ix, query, (size_t)k, res, nullptr);
+    g_probe_trace = nullptr;
+    const long n = (long)tr.size();
+    std::memcpy(out, tr.data(), (size_t)std::min(n, cap) * 4);
+    return n;
 }
 
 int orc_neighbor_count(void* h, uint32_t vertex) {

@@ -10,10 +10,11 @@ def _cfg(name):
     return bench.CONFIGS[name]
 
 
-def bytes_per_dist(name):
+def bytes_per_dist(name, bits=0):
     c = _cfg(name)
+    bits = bits or c["bits"]
     D = 1 << (c["dim"] - 1).bit_length()
-    return D * c["bits"] // 8 + (20 if c["bits"] > 1 else 18)
+    return D * bits // 8 + (20 if bits > 1 else 18)
 
 
 def bytes_per_exact(name):

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--index", default="", help="index file (default: the bench cache of --config)")
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--bits", type=int, default=0, help="0 = the config's bit width (bench.py --bits)")
     ap.add_argument("--product", action="store_true", help="run the shipped library (no timers), e.g. under rocprofv3 --pmc")
     args = ap.parse_args()
     if args.build:
@@ -43,7 +44,9 @@ def main():
     import torch
     import bench
     from cphnsw_mi355x import CPIndex
-    cfg = bench.CONFIGS[args.config]
+    cfg = dict(bench.CONFIGS[args.config])
+    if args.bits:
+        cfg["bits"] = args.bits
 
     class _A:
         workdir = os.environ.get("CPH_BENCH_DIR", "/tmp/cph_bench")
@@ -62,7 +65,7 @@ def main():
         torch.cuda.synchronize()
         best = min(best, idx.last_search_stats()["kernel_us"])
     import json
-    print(json.dumps({"lib": "product" if args.product else os.path.basename(args.lib), "config": args.config, "nq": args.nq, "k": args.k,
+    print(json.dumps({"lib": "product" if args.product else os.path.basename(args.lib), "config": args.config, "bits": cfg["bits"], "nq": args.nq, "k": args.k,
                       "best_kernel_us": best, "stats": idx.last_search_stats()}))
 
 

@@ -47,9 +47,11 @@ def main():
     if args.json and stats and "FETCH_SIZE" in means and "WRITE_SIZE" in means:
         st = stats["stats"]
         import bench_shapes
-        alg = st["expansions"] * 32 * bench_shapes.bytes_per_dist(stats["config"]) + st["exact_l2"] * bench_shapes.bytes_per_exact(stats["config"])
+        bits = stats.get("bits", 0)
+        alg = st["expansions"] * 32 * bench_shapes.bytes_per_dist(stats["config"], bits) + st["exact_l2"] * bench_shapes.bytes_per_exact(stats["config"])
         hbm = 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0
-        rec = {"config": stats["config"], "k": stats["k"], "nq": stats["nq"], "expansions": st["expansions"],
+        rec = {"config": stats["config"], "k": stats["k"], "bits": bits or bench_shapes._cfg(stats["config"])["bits"], "nq": stats["nq"],
+               "kernel_us": st.get("kernel_us"), "expansions": st["expansions"],
                "exact_l2": st["exact_l2"], "algorithmic_bytes": alg, "fetch_size_kb": means["FETCH_SIZE"],
                "write_size_kb": means["WRITE_SIZE"], "hbm_bytes": hbm, "hbm_bytes_over_algorithmic": hbm / alg,
                "per_expansion": {c: means[c] / st["expansions"] for c in means}}
