@@ -398,15 +398,22 @@ __device__ __forceinline__ void lower_bounds_split(const QP& q, const LaneEst& v
 }
 
 // The estimate half of stage2_est / est_and_lower (BW >= 2), for callers that took the bounds from lower_bounds_split.
+// `tiny` = dqp < kEpsSmall, which the caller knows as a wave-uniform fact (dqp is the popped vertex' distance): tested on
+// the per-lane value it compiled to an exec-mask save / branch / restore around the whole estimate.  The division is made
+// unconditionally and its result selected -- written as `good ? x / ipq : 0` the compiler branches around it (another
+// exec-mask round and a reload of the query constants on the scalar unit, which this kernel runs out of); the quotient
+// of a lane with ipq <= 1e-10 is discarded, the others are the same IEEE division.
 template <int BW>
-__device__ __forceinline__ float stage2_est_only(const QP& q, const LaneEst& v, float dqp, const TailLanes& tl) {
+__device__ __forceinline__ float stage2_est_only(const QP& q, const LaneEst& v, float dqp, const TailLanes& tl, bool tiny) {
     static_assert(BW >= 2, "N-bit path");
-    if (dqp < kEpsSmall) return __fmaf_rn(v.nop, v.nop, dqp);
+    if (tiny) return __fmaf_rn(v.nop, v.nop, dqp);
     constexpr float K = (float)((1u << BW) - 1);
     constexpr float invK = 1.0f / K;
     const float ipn = ip_approx_est(q.A * invK, (float)v.nbit, q.B * invK, (float)v.wpop, q.C, tl);
     const float ipq = vmaxf(v.ip_qo, q.floor);
-    float e = (ipq > kEpsMedium) ? (ipn - v.ip_cp) / ipq : 0.0f;
+    float e = (ipn - v.ip_cp) / ipq;
+    asm volatile("" : "+v"(e));
+    e = (ipq > kEpsMedium) ? e : 0.0f;
     e = __fmaf_rn(q.affine_a, e, q.affine_b);
     float dist = __fmaf_rn(v.nop, v.nop, dqp);
     dist = __fmaf_rn(-(2.0f * v.nop), e, dist);

@@ -597,9 +597,9 @@ __device__ __forceinline__ float bcast_f32(float v) {
 }
 
 // LDS carve-up (bytes): qm[PW*16] | qv[D*4] | vec[512 or D*4] (popped vertex's vector, LDS-DMA target) |
-// exact[128] | list[64] | slack[128] | ratio[16] | nn[k*8] |
+// exact[128] | list[64] | slack[128] | ratio[16] | totals[80] | nn[k*8] |
 // beam top levels (kBeamLds+1) x 16
-constexpr uint32_t kLdsTail = 128 + 64 + 128 + 16;            // exact | list | slack | ratio
+constexpr uint32_t kLdsTail = 128 + 64 + 128 + 16 + 80;       // exact | list | slack | ratio | totals
 // vec[] holds the popped vertex' whole vector in the instantiations with a compile-time D (LDS-DMA target)
 __host__ __device__ inline uint32_t search_vec_bytes(uint32_t D, bool static_d) { return static_d ? D * 4 : 512; }
 __host__ __device__ inline bool search_static_d(uint32_t D) { return D == 128 || D == 1024; }
@@ -664,6 +664,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
     uint8_t* s_list = fixed + vsz + 128;
     float* s_slack = reinterpret_cast<float*>(fixed + vsz + 192);
     double* s_ratio = reinterpret_cast<double*>(fixed + vsz + 320);   // [2]
+    // The work counters of this wave's queries are summed here and reach the statistics line in HBM ONCE, when the wave
+    // leaves: six atomics per query on one line from six thousand waves are a queue in the L2's atomic unit that every
+    // query's first load has to wait behind (vmcnt counts them).
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(fixed + vsz + 336);   // [10], indexed like stats[]
+    if (lane < 10) s_tot[lane] = 0ull;
     Result* nn = reinterpret_cast<Result*>(fixed + vsz + kLdsTail);
     NnLds nnw;
     nnw.l = (lds_u32x2*)(fixed + vsz + kLdsTail);
@@ -999,10 +1004,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                     // both lower bounds at once, one per lane half (see lower_bounds_split); dqp is the popped vertex's
                     // distance, the same in every lane
                     float lo1 = 0.0f, lo2 = 0.0f;
-                    if (!(bcast_f32(dqp) < kEpsSmall)) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2, tl);
+                    const bool tiny = bcast_f32(dqp) < kEpsSmall;
+                    if (!tiny) lower_bounds_split<BW>(qp, v, dqp, sq, lane, lo1, lo2, tl);
                     // any_survivor (:178-187) ranges over ALL the list's neighbours, estimated before or not
                     if (__builtin_expect(nn_sz < k || __any(fetched && valid && lo1 < worst0), 1)) {
-                        est = stage2_est_only<BW>(qp, v, dqp, tl);
+                        est = stage2_est_only<BW>(qp, v, dqp, tl, tiny);
                         lower = lo2;
                     } else if constexpr (!kProbeFirst) {            // the reference's skipped batch (:201-205)
                         est = FMAX;
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                         // of the branch every expansion waits on.)
                         LaneEst w = v;
                         asm volatile("" : "+v"(w.nbit));
-                        est = stage2_est_only<BW>(qp, w, dqp, tl);
+                        est = stage2_est_only<BW>(qp, w, dqp, tl, tiny);
                         lower = lo2;
                         const bool acts = fetched && !(lo2 >= worst0) && (est < worst0 || est < gamma_q * worst0);
                         if (__any(acts)) return false;
@@ -1278,18 +1284,16 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             CPH_COLD(out_count)[qi] = nn_final;
             // bits 0..7: QueryStatus; bits 8..31: vertices expanded (per-query work, for load analysis)
             CPH_COLD(status)[qi] = (overflow ? kStatusOverflow : kStatusOk) | (st_exp << 8);
+            s_tot[0] += st_exp;
+            s_tot[1] += st_exact;
+            s_tot[2] += st_new;
+            s_tot[3] += st_push;
+            s_tot[4] += st_skip;
+            s_tot[7] += st_allseen;
+            if (stage2_redo) s_tot[8] += 1;                       // queries handed to the re-run launch for a stage-2 decision
+            s_tot[9] += st_undecided;
+#if defined(CPH_PHASE_TIMERS) || defined(CPH_TRAFFIC_STATS)
             unsigned long long* stats = CPH_COLD(stats);
-            atomicAdd(&stats[0], (unsigned long long)st_exp);
-            atomicAdd(&stats[1], (unsigned long long)st_exact);
-            atomicAdd(&stats[2], (unsigned long long)st_new);
-            atomicAdd(&stats[3], (unsigned long long)st_push);
-            // (guarded: an instantiation that can never skip would add a constant zero, which the compiler turns into an
-            // atomic LOAD of this contended line -- a synchronous round trip per query that cost the probe-first kernel 15 %)
-            if (st_skip) atomicAdd(&stats[4], (unsigned long long)st_skip);
-            atomicAdd(&stats[7], (unsigned long long)st_allseen);
-#if !defined(CPH_PHASE_TIMERS) && !defined(CPH_TRAFFIC_STATS)
-            if (stage2_redo) atomicAdd(&stats[8], 1ull);          // queries handed to the re-run launch for a stage-2 decision
-            if (st_undecided) atomicAdd(&stats[9], (unsigned long long)st_undecided);
 #endif
 #ifdef CPH_PHASE_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&stats[8 + i], tph[i]);
@@ -1298,7 +1302,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             for (int i = 0; i < 8; ++i) { if (i == 6) atomicMax(&stats[8 + i], trf[i]); else atomicAdd(&stats[8 + i], trf[i]); }
 #endif
             if (overflow) {
-                atomicAdd(&stats[5], 1ull);
+                s_tot[5] += 1;
                 uint32_t* redo = CPH_COLD(redo);
                 if (redo) redo[atomicAdd(CPH_COLD(redo_count), 1u)] = qi;
             }
@@ -1312,6 +1316,17 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             for (uint32_t j = lane; j < log_count; j += 64) bm[logi[j] >> 5] = 0u;
         }
         __syncthreads();
+    }
+    // the wave leaves: its totals go to the statistics line
+#if defined(CPH_PHASE_TIMERS) || defined(CPH_TRAFFIC_STATS)
+    if (lane < 8) {            // (stats[8..15] carry the diagnostic counters in these builds)
+#else
+    if (lane < 10) {
+#endif
+        const unsigned long long v = s_tot[lane];
+        // (an atomic add of a constant zero is turned into an atomic LOAD of the line by the compiler -- a synchronous
+        // round trip; the values here are not constants, and zeros are skipped anyway)
+        if (v != 0ull && lane != 6) atomicAdd(&CPH_COLD(stats)[lane], v);
     }
 }
 

@@ -11,6 +11,7 @@
 // This file is compiled with -ffp-contract=off; each fused multiply-add is explicit and
 // sits where the compiled reference has one.
 #pragma once
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -121,9 +122,11 @@ inline void lut_to_qu(const uint8_t* lut, size_t D, uint8_t* qu) {
     for (size_t d = 0; d < D; ++d) qu[d] = lut[(d / 4) * 16 + (1u << (d % 4))];
 }
 
-// A file that appears under its final name only when it is complete: written as <path>.tmp.<pid>, flushed and closed
-// with the results checked, then renamed over the target.  A handle that serves an index out of a mapping of
-// `path` keeps its (old) inode; a failed or interrupted save leaves the previous file untouched.
+// A file that appears under its final name only when it is complete: written as <path>.tmp.<pid>, flushed, synced to
+// the device (fsync: a rename can reach the disk before the data it names, and a crash in between would leave a
+// truncated file under the final name) and closed with the results checked, then renamed over the target and the
+// directory entry synced.  A handle that serves an index out of a mapping of `path` keeps its (old) inode; a failed or
+// interrupted save leaves the previous file untouched.
 struct AtomicFile {
     std::string path, tmp;
     FILE* f = nullptr;
@@ -137,12 +140,17 @@ struct AtomicFile {
         if (b && std::fwrite(p, 1, b, f) != b) throw std::runtime_error("Write error: " + path);
     }
     void commit() {
-        const bool ok = std::fflush(f) == 0;
+        const bool ok = std::fflush(f) == 0 && ::fsync(fileno(f)) == 0;
         const bool closed = std::fclose(f) == 0;
         f = nullptr;
         if (!ok || !closed) throw std::runtime_error("Write error: " + path);
-        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("Cannot open file for writing: " + path);
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("Cannot rename the finished file into place: " + path);
         tmp.clear();
+        // the new directory entry (best effort: some file systems refuse to open a directory for this)
+        const size_t slash = path.find_last_of('/');
+        const std::string dir = slash == std::string::npos ? "." : (slash == 0 ? "/" : path.substr(0, slash));
+        const int dfd = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY);
+        if (dfd >= 0) { (void)::fsync(dfd); ::close(dfd); }
     }
     ~AtomicFile() {
         if (f) std::fclose(f);

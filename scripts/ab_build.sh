@@ -18,7 +18,7 @@ declare -A V=(
   [noloopwait]="-DCPH_NO_LOOPHEAD_WAIT"                  # no vmcnt(0) at the head of the expansion loop
   [w5]="-DCPH_SEARCH_WAVES_PER_SIMD_128=5"               # five waves per SIMD (96 VGPRs) for D = 128
   [w7]="-DCPH_SEARCH_WAVES_PER_SIMD_128=7"               # seven waves per SIMD (72 VGPRs)
-  [nogroupfetch]="-DCPH_PF_NO_GROUP_FETCH"               # probe first fetches the new neighbours' lanes only (no 8-lane groups)
+  [trace]="-DCPH_SEARCH_TRACE"                           # host-side timing of the coalesced cph_search launches (stderr at cph_destroy)
 )
 if [ "$1" = "--list" ] || [ -z "$1" ]; then for k in "${!V[@]}"; do printf "%-14s %s\n" "$k" "${V[$k]}"; done | sort; exit 0; fi
 FLAGS=$(python3 -c "import sys; sys.path.insert(0,'rabitq-ann-search_amd'); from cphnsw_mi355x import build as b; print(' '.join(b.FLAGS))")
