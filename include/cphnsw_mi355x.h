@@ -25,7 +25,11 @@
  * thrown.  CPH_INVALID_ARGUMENT maps to Python ValueError (std::invalid_argument),
  * CPH_RUNTIME_ERROR to RuntimeError (std::runtime_error), CPH_OUT_OF_MEMORY to MemoryError.
  * The caller owns all buffers; the library owns the handle.  A handle is bound to one HIP
- * device; concurrent searches on one handle are serialised internally.
+ * device.  Threads: every entry point may be called from any thread.  Concurrent cph_search callers on one handle
+ * are COALESCED into shared launches (the reference answers them in parallel under a shared lock,
+ * src/bindings.cpp:146-175, api/hnsw_index.hpp:172): a caller that finds a free leader slot takes everybody queued
+ * so far with the same k into one launch; each gets its own rows.  The other entry points serialise on the handle
+ * (cph_search_batch_device only while it enqueues).  Knobs: CPH_LEADER_SLOTS (default 3), CPH_GATHER_US (150).
  * Returned ids are the reference's internal (post-BFS-reorder) node ids.
  */
 #ifndef CPHNSW_MI355X_H
