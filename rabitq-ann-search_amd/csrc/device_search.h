@@ -18,8 +18,11 @@
 //    {est < worst at loop entry} is a superset of the lanes the serial loop will rerank;
 //  * an expansion whose neighbours are all estimated already has no observable effect beyond
 //    the result-heap push of the popped vertex: its FastScan arithmetic is skipped;
-//  * the kernel is instruction-issue bound: there is no software prefetch, the
-//    probe is a load (atomics only for new ids), shuffles are DPP / v_permlane32_swap.
+//  * what bounds it depends on the workload: on the SIFT-like benchmark a launch lasts as long as its
+//    longest query and the steady state shares the CU's one scalar unit between 24 waves; on the recall-gate workloads
+//    (beams of thousands of entries, no id locality) it is HBM-bound on the bytes it actually moves.  Hence: no
+//    software prefetch, the probe is a load (atomics only for new ids), shuffles are DPP / v_permlane32_swap, and
+//    everything a lane can do without an exec-mask round trip on the scalar unit is done that way.
 #pragma once
 #include <cstddef>
 #include <hip/hip_runtime.h>
@@ -697,13 +700,11 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
     // invalidates cost bandwidth and issue slots, and the pop already runs under the block's own latency.  (Earlier:
     // switching it on when a larger batch starts to drain, or per query for the head or the tail of the launch order,
     // were 1-4 % slower on the 10k batch or far worse, profiles/r2_lat_sweep.jsonl.)
-    // What bounds the throughput phase is instruction issue, not latency: per expansion a wave issues ~320 vector and
-    // ~270 scalar instructions (profiles/r2_pmc_search_summary.txt), and with six waves on a SIMD that is ~85 % of
-    // the SIMD's vector issue slots (one wave64 instruction per four cycles) while the queue is full.  Hiding more
-    // latency per wave therefore buys nothing -- tried and measured on one box: issuing the next expansion's loads
-    // before this expansion's beam pushes (the next top is known without doing them) 2.36 -> 2.46 ms per 10k
-    // queries; doing the same at a second issue site made the register allocator copy the loaded registers at the
-    // loop head, i.e. wait for them: 2.50 ms.  Fewer instructions per expansion is the only lever left.
+    // Hiding more latency per wave buys nothing either -- tried and measured on one box: issuing the next expansion's loads
+    // before this expansion's beam pushes (the next top is known without doing them) 2.36 -> 2.46 ms per 10k queries; doing
+    // the same at a second issue site made the register allocator copy the loaded registers at the loop head, i.e. wait
+    // for them: 2.50 ms.  Round 4: raising the priority of a wave whose query has passed 200 / 300 / 400 expansions
+    // (s_setprio; a launch lasts as long as its longest query) changed nothing either way.
     const uint32_t* nq_dev = CPH_COLD(nq_dev);
     const uint32_t nq = nq_dev ? *nq_dev : CPH_COLD(nq);
     for (;;) {
