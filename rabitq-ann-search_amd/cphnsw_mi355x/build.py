@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libcphnsw_mi355x.so")
 SOURCES = ["cphnsw_mi355x.hip"]
-HEADERS = ["cph_core.h", "builder.h", "builder_host.h", "host_parallel.h", "builder_pipeline.h", "device_knn.h", "device_knn_sym.h", "device_build.h", "device_buf.h", "native_file.h", "device_encode.h", "device_fastscan.h", "device_search.h", "device_stream.h", "device_heap_test.h", "host_index.h"]
+HEADERS = ["cph_core.h", "builder.h", "builder_host.h", "host_parallel.h", "search_coalescer.h", "builder_pipeline.h", "device_knn.h", "device_knn_sym.h", "device_build.h", "device_buf.h", "native_file.h", "device_encode.h", "device_fastscan.h", "device_search.h", "device_stream.h", "device_heap_test.h", "host_index.h"]
 # -ffp-contract=off: every fused multiply-add in the sources is explicit and placed where the
 # reference has one; the compiler must not add or remove any.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=off",

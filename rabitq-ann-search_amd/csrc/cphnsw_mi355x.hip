@@ -30,6 +30,7 @@
 #include "device_heap_test.h"
 #include "host_index.h"
 #include "host_parallel.h"
+#include "search_coalescer.h"
 #include "native_file.h"
 #include "builder_pipeline.h"
 
@@ -131,21 +132,7 @@ struct BatchSet {
 };
 constexpr int kStatWords = 18;
 constexpr int kMaxBatchSets = 4;
-constexpr int kLeaderSlots = 4;             // launches of coalesced cph_search callers that may be in flight together
-constexpr uint64_t kLeaderGroup = 16;       // callers per such launch at most
 constexpr uint64_t kSmallBatch = 32;        // batches up to this size take the copy-free path of cph_search / cph_search_batch
-
-// One caller of cph_search waiting for its answer (see coalesced_search).
-struct SearchReq {
-    const float* query;
-    uint64_t k;            // already clamped to >= 1
-    int64_t* ids;
-    float* dist;
-    uint64_t* m;
-    int rc = CPH_OK;
-    std::string err;
-    bool done = false;
-};
 
 struct cph_index {
     uint64_t dim = 0;
@@ -192,25 +179,15 @@ struct cph_index {
     bool pf_dense = false;             // ... or suspended: the last batches found more than 6 new neighbours per expansion
     std::mutex mu;
     // concurrent cph_search callers (the reference: shared lock, T threads search in parallel, api/hnsw_index.hpp:172):
-    // whoever finds no launch in flight leads one for everybody queued so far
-    std::mutex qmu;
-    std::condition_variable qcv;
-    std::deque<SearchReq*> waiting;
-    // a leader slot = a stream, a pinned device-mapped I/O buffer and a batch set (sets[kMaxBatchSets + i]) of its own
+    // whoever finds no launch in flight leads one for everybody queued so far (search_coalescer.h: the policy, host only)
+    SearchCoalescer coal;
+    // a leader slot's resources: a stream, a pinned device-mapped I/O buffer and a batch set (sets[kMaxBatchSets + i])
     struct LeaderSlot {
-        bool busy = false;
         hipStream_t stream = nullptr;
         uint8_t* pin = nullptr;
         uint8_t* pin_dev = nullptr;
         size_t pin_bytes = 0;
-        size_t last_group = 0;     // callers its previous launch answered
     } leaders[kLeaderSlots];
-    int gathering = 0;             // leaders holding their launch back for callers that are about to come back
-    // Measured on C2 with 16 / 32 caller threads (profiles/r4_concurrent_search.md): 3 slots and a 150-us gathering window
-    // -- few, large launches: one launch answers 1 or 16 callers in nearly the same time (it lasts as long as its
-    // longest query), while more than three small launches in flight slow each other down.
-    int n_leaders = 3;             // slots in use (CPH_LEADER_SLOTS, at most kLeaderSlots)
-    int gather_us = 150;           // CPH_GATHER_US
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
 };
@@ -724,8 +701,8 @@ int cph_create(uint64_t dim, uint64_t bits, int device, cph_index** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cus = prop.multiProcessorCount;
         if (const char* e = getenv("CPH_QUERY_ORDER")) h->order_queries = atoi(e) != 0;
-        if (const char* e = getenv("CPH_LEADER_SLOTS")) h->n_leaders = std::max(1, std::min(kLeaderSlots, atoi(e)));
-        if (const char* e = getenv("CPH_GATHER_US")) h->gather_us = std::max(0, atoi(e));
+        if (const char* e = getenv("CPH_LEADER_SLOTS")) h->coal.n_slots = std::max(1, std::min(kLeaderSlots, atoi(e)));
+        if (const char* e = getenv("CPH_GATHER_US")) h->coal.gather_us = std::max(0, atoi(e));
         if (const char* e = getenv("CPH_WAVES_PER_CU")) { h->waves_per_cu = (uint32_t)std::max(1, atoi(e)); h->waves_from_env = true; }
         *out = h;
     });
@@ -1307,61 +1284,6 @@ static void run_search_group(cph_index* h, cph_index::LeaderSlot& ls, const std:
     CPH_TR(0, 1); CPH_TR(1, n); CPH_TR(2, t1 - t0); CPH_TR(3, t2 - t1); CPH_TR(4, t3 - t2); CPH_TR(5, now_ns() - t3);
 }
 
-// Concurrent callers of cph_search on one handle.  The reference answers them in parallel under a shared lock
-// (src/bindings.cpp:146-175, api/hnsw_index.hpp:172); a GPU answers them best TOGETHER: a caller that finds a free
-// leader slot takes everybody who queued up so far (same k, at most kLeaderGroup) into one launch; callers arriving
-// while every slot is in flight wait on the condition variable and are gathered by the next leader.  No spinning
-// kernel, no extra thread; a lone caller pays one uncontended mutex more than before.
-static void coalesced_search(cph_index* h, SearchReq& r) {
-    std::unique_lock<std::mutex> lk(h->qmu);
-    h->waiting.push_back(&r);
-    if (h->gathering) h->qcv.notify_all();
-    while (!r.done) {
-        int slot = -1;
-        for (int i = 0; i < h->n_leaders; ++i) if (!h->leaders[i].busy) { slot = i; break; }
-        // (our request may already ride in another leader's launch: then there is nothing to lead)
-        const bool queued = std::find(h->waiting.begin(), h->waiting.end(), &r) != h->waiting.end();
-        if (slot < 0 || !queued) {
-            h->qcv.wait(lk);
-            continue;
-        }
-        h->leaders[slot].busy = true;
-        // Callers that block on their answers come back together: if this slot's previous launch answered several, hold
-        // the launch for up to gather_us while the queue fills to that size (a lone caller never waits).
-        if (h->leaders[slot].last_group > 1 && h->waiting.size() < h->leaders[slot].last_group) {
-            const size_t want = std::min<size_t>(h->leaders[slot].last_group, kLeaderGroup);
-            ++h->gathering;
-            h->qcv.wait_for(lk, std::chrono::microseconds(h->gather_us), [&] { return h->waiting.size() >= want; });
-            --h->gathering;
-            // (the mutex was released meanwhile: another leader may have taken this caller along)
-            if (std::find(h->waiting.begin(), h->waiting.end(), &r) == h->waiting.end()) {
-                h->leaders[slot].busy = false;
-                h->qcv.notify_all();
-                continue;
-            }
-        }
-        std::vector<SearchReq*> group;
-        const uint64_t kk = r.k;
-        const uint64_t cap = std::max<uint64_t>(1, std::min<uint64_t>(kLeaderGroup, (1u << 20) / kk));
-        for (auto it = h->waiting.begin(); it != h->waiting.end() && group.size() < cap;) {
-            if ((*it)->k == kk) { group.push_back(*it); it = h->waiting.erase(it); } else ++it;
-        }
-        lk.unlock();
-        int rc = CPH_OK;
-        std::string err;
-        try {
-            run_search_group(h, h->leaders[slot], group);
-        } catch (const std::invalid_argument& e) { rc = CPH_INVALID_ARGUMENT; err = e.what();
-        } catch (const std::bad_alloc&) { rc = CPH_OUT_OF_MEMORY; err = "out of memory";
-        } catch (const std::exception& e) { rc = CPH_RUNTIME_ERROR; err = e.what(); }
-        lk.lock();
-        for (SearchReq* g : group) { g->rc = rc; g->err = err; g->done = true; }
-        h->leaders[slot].last_group = group.size();
-        h->leaders[slot].busy = false;
-        h->qcv.notify_all();
-    }
-}
-
 int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
                uint64_t* m) {
     SearchReq r{};
@@ -1371,7 +1293,8 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
         const uint64_t kk = std::max<uint64_t>(k, 1);  // api/hnsw_index.hpp:187
         if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
         r.query = query; r.k = kk; r.ids = ids; r.dist = dist; r.m = m;
-        coalesced_search(h, r);
+        // concurrent callers are gathered into shared launches (search_coalescer.h); the status codes it records are cph_status
+        h->coal.submit(r, [&](int slot, const std::vector<SearchReq*>& group) { run_search_group(h, h->leaders[slot], group); });
     });
     if (rc != CPH_OK) return rc;
     return r.rc == CPH_OK ? CPH_OK : fail(r.rc, r.err);

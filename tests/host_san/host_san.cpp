@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "../../rabitq-ann-search_amd/csrc/search_coalescer.h"
 #include "../../rabitq-ann-search_amd/csrc/builder_host.h"
 #include "../../rabitq-ann-search_amd/csrc/host_index.h"
 #include "../../rabitq-ann-search_amd/csrc/host_parallel.h"
@@ -331,8 +332,81 @@ static int run_threads_mode() {
     return 0;
 }
 
+// ---- the coalescing policy of concurrent cph_search callers (csrc/search_coalescer.h) with a stand-in launch -----
+// T threads x calls; the "launch" answers every member of its group from the member's own query value after a short
+// sleep (so that callers pile up), fails on purpose for k == 7, and records group sizes.  Every caller must be
+// answered exactly once, with ITS answer, errors must reach every member of the failing group, a group never mixes
+// k, never exceeds the cap, and no more launches than slots are in flight.
+static int run_coalescer_mode() {
+    using namespace cph;
+    SearchCoalescer co;
+    co.n_slots = 3;
+    co.gather_us = 100;
+    std::atomic<int> in_flight{0}, max_in_flight{0}, launches{0}, max_group{0}, answered{0}, mixed{0};
+    auto run = [&](int slot, const std::vector<SearchReq*>& g) {
+        const int now = ++in_flight;
+        int prev = max_in_flight.load();
+        while (now > prev && !max_in_flight.compare_exchange_weak(prev, now)) {}
+        ++launches;
+        int pg = max_group.load();
+        while ((int)g.size() > pg && !max_group.compare_exchange_weak(pg, (int)g.size())) {}
+        REQUIRE(slot >= 0 && slot < co.n_slots);
+        REQUIRE(!g.empty() && g.size() <= kLeaderGroup);
+        for (SearchReq* r : g) if (r->k != g[0]->k) ++mixed;
+        std::this_thread::sleep_for(std::chrono::microseconds(200 + 30 * g.size()));
+        if (g[0]->k == 7) { --in_flight; throw std::runtime_error("stand-in launch failed"); }
+        for (SearchReq* r : g) {
+            r->ids[0] = (int64_t)(r->query[0] * 2.0f);      // "the answer" = a function of the caller's own query
+            r->dist[0] = r->query[0] + (float)r->k;
+            *r->m = 1;
+        }
+        --in_flight;
+    };
+    const int T = 12, calls = 150;
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+        for (int c = 0; c < calls; ++c) {
+            float q = (float)(t * 1000 + c);
+            int64_t id = -1;
+            float d = -1.0f;
+            uint64_t m = 0;
+            SearchReq r;
+            r.query = &q; r.k = (uint64_t)((t % 4 == 3) ? 7 : (t % 3 == 0 ? 1 : 10)); r.ids = &id; r.dist = &d; r.m = &m;
+            co.submit(r, run);
+            ++answered;
+            if (r.k == 7) { if (r.rc != 2 || r.err != "stand-in launch failed") ++bad; }
+            else if (r.rc != 0 || m != 1 || id != (int64_t)(q * 2.0f) || d != q + (float)r.k) ++bad;
+        }
+    });
+    for (auto& x : th) x.join();
+    REQUIRE(answered.load() == T * calls);
+    REQUIRE(bad.load() == 0);
+    REQUIRE(mixed.load() == 0);
+    REQUIRE(max_in_flight.load() <= co.n_slots);
+    REQUIRE(launches.load() < T * calls);          // callers WERE gathered
+    REQUIRE(max_group.load() > 1);
+    REQUIRE(co.waiting.empty() && co.gathering == 0);
+    for (int i = 0; i < co.n_slots; ++i) REQUIRE(!co.slots[i].busy);
+    // a lone caller is its own leader and never waits for the window
+    {
+        float q = 5.0f; int64_t id = 0; float d = 0; uint64_t m = 0;
+        SearchReq r; r.query = &q; r.k = 10; r.ids = &id; r.dist = &d; r.m = &m;
+        for (auto& sl : co.slots) sl.last_group = 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        co.gather_us = 200000;
+        co.submit(r, run);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        REQUIRE(r.rc == 0 && id == 10 && ms < 100.0);
+    }
+    std::printf("coalescer: ok (%d callers in %d launches, largest group %d, at most %d in flight)\n", T * calls, launches.load(),
+                max_group.load(), max_in_flight.load());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "coalescer") return run_coalescer_mode();
     if (mode == "files" && argc == 4) return run_files(argv[2], argv[3]);
     if (mode == "builder") return run_builder();
     if (mode == "threads") return run_threads_mode();

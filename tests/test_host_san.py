@@ -6,8 +6,9 @@ csrc/host_parallel.h, and is built twice with plain g++:
   * -fsanitize=address,undefined : good, truncated, corrupted-header, oversized-count and bit-flipped index files
     (what the reference's loader, api/hnsw_index.hpp:305-443, trusts, ours must reject with an exception); the
     builder's host statistics and the concurrent upper-layer insertion;
-  * -fsanitize=thread            : UpperLayers::build on 8 threads (per-vertex spin locks) and parallel_for's
-    exception path.
+  * -fsanitize=thread            : UpperLayers::build on 8 threads (per-vertex spin locks), parallel_for's
+    exception path, and the leader / follower policy of concurrent cph_search callers (csrc/search_coalescer.h) with a
+    stand-in launch.
 A sanitizer report makes the binary exit non-zero (halt_on_error / -fno-sanitize-recover)."""
 import os
 import shutil
@@ -64,3 +65,15 @@ def test_builder_host_code_under_asan_ubsan(asan_exe):
 
 def test_upper_layers_and_parallel_for_under_tsan(tsan_exe):
     assert "threads: ok" in _run([tsan_exe, "threads"])
+
+
+def test_search_coalescer_under_tsan(tsan_exe):
+    """The leader / follower policy that gathers concurrent cph_search callers into shared launches
+    (csrc/search_coalescer.h), 12 threads x 150 calls with a stand-in launch: every caller answered once with its own
+    answer, errors reach every member of a failing group, groups never mix k, never more launches in flight than slots --
+    and ThreadSanitizer sees no race."""
+    assert "coalescer: ok" in _run([tsan_exe, "coalescer"])
+
+
+def test_search_coalescer_under_asan(asan_exe):
+    assert "coalescer: ok" in _run([asan_exe, "coalescer"])
