@@ -844,8 +844,9 @@ def main():
         # Every rank takes the same decision (MAX over ranks of the trial times).
         tuning = {}
         for ns in (2, 4):
-            trial_steps = max(2, min(8, args.steps))
-            el, _, _ = timed_region(configure(ns), trial_steps, 0, False, use_dist, dist, torch.cuda.synchronize, dev, prime=ns)
+            # (24 steps behind two warm-up steps: the two settings are 2-4 % apart, an 8-step trial from a cold start could not tell)
+            trial_steps = max(4, min(24, 2 * args.steps))
+            el, _, _ = timed_region(configure(ns), trial_steps, 2, False, use_dist, dist, torch.cuda.synchronize, dev, prime=ns)
             tuning[ns] = el / trial_steps
         n_streams = min(tuning, key=tuning.get)
         log(f"[bench] rank {rank}: batches in flight: trial " + ", ".join(f"{ns} sets {1e3 * t:.3f} ms/step" for ns, t in tuning.items())
