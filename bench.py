@@ -727,7 +727,8 @@ def main():
     ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 0)), help="override the config's n")
     ap.add_argument("--nq-per-gpu", type=int, default=0)
     ap.add_argument("--stream-blocks", type=int, default=0)
-    ap.add_argument("--cpu-queries", type=int, default=2_000)
+    ap.add_argument("--cpu-queries", type=int, default=10_000,
+                    help="queries of the batch the CPU baseline times and the parity check compares (the legs pass smaller samples)")
     ap.add_argument("--counter-queries", type=int, default=2_000,
                     help="queries of the CPU sample whose per-query expansion counts / totals are also checked against the oracle's counters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
