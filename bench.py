@@ -727,8 +727,9 @@ def main():
     ap.add_argument("--n-index", type=int, default=int(os.environ.get("CPH_BENCH_N", 0)), help="override the config's n")
     ap.add_argument("--nq-per-gpu", type=int, default=0)
     ap.add_argument("--stream-blocks", type=int, default=0)
-    ap.add_argument("--cpu-queries", type=int, default=10_000,
-                    help="queries of the batch the CPU baseline times and the parity check compares (the legs pass smaller samples)")
+    ap.add_argument("--cpu-queries", type=int, default=0,
+                    help="queries of the batch the CPU baseline times and the parity check compares; 0 = per config: the whole "
+                         "10,000-query batch at C2, bounded samples where the reference runs at 100-8,000 QPS")
     ap.add_argument("--counter-queries", type=int, default=2_000,
                     help="queries of the CPU sample whose per-query expansion counts / totals are also checked against the oracle's counters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -790,6 +791,8 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.bits:
         cfg["bits"] = args.bits
+    if args.cpu_queries <= 0:
+        args.cpu_queries = {"c2": 10_000, "c3": 1_000, "c4": 500, "recall": 2_000, "recall1m": 200}.get(args.config, 1_000)
     n = args.n_index or cfg["n"]
     dim, bits = cfg["dim"], cfg["bits"]
     D = 1 << (dim - 1).bit_length()
