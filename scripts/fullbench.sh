@@ -1,7 +1,7 @@
 #!/bin/bash
 # the driver's default command, as the driver runs it (fresh box: builds every index), with its wall time
 export TMPDIR=/tmp
-O=gpurun_out/r4_fullbench; mkdir -p $O
+O=${1:-gpurun_out/fullbench}; mkdir -p $O
 ( while true; do sleep 60; echo "[keepalive] $(date +%T)" >> $O/progress.log; done ) &
 KA=$!
 t0=$(date +%s)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the GPU parity suite, then the C2 search kernel of this tree against a frozen library (build/libcph_<ref>.so) on the same box
-#     scripts/r4_gpu_suite.sh <outdir> [ref-lib] [extra pytest args]
+#     scripts/gpu_suite.sh <outdir> [ref-lib]      (ref-lib: e.g. a build of the previous round's tree, see scripts/ab_build.sh)
 export TMPDIR=/tmp
 O=${1:-gpurun_out/suite}; REF=${2:-build/libcph_r3.so}; mkdir -p $O
 timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log; [ $rc -eq 0 ] || exit 1

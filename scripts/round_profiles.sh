@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU suite, concurrent-caller throughput (ours and the reference), and the rocprofv3 kernel trace of the C2 bench command
 export TMPDIR=/tmp
-O=gpurun_out/r4_profiles; mkdir -p $O
+O=${1:-gpurun_out/round_profiles}; mkdir -p $O
 timeout -k 10 1000 python3 -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; tail -3 $O/pytest.log; [ $rc -eq 0 ] || exit 1
 python3 bench.py --config c2 --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/prep_c2.json 2> $O/prep_c2.err || { tail -5 $O/prep_c2.err; exit 1; }
 python3 scripts/concurrent_search.py c2 | tee $O/concurrent_c2.json
