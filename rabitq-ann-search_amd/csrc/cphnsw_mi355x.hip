@@ -194,11 +194,11 @@ struct cph_index {
 
 namespace {
 
-// The batch launch of this index runs the probe-first instantiation of the search kernel (4-bit codes at D = 128): it sees
-// only the new neighbours' codes, so a query whose stage-2 decision needs the others, and every index with short neighbour
-// lists (flags bit 1: scalar tails), goes to the instantiation without it.
+// The batch launch of this index runs the probe-first instantiation of the search kernel (D = 128): it sees only the new
+// neighbours' codes, so a query whose stage-2 decision needs the others, and every index with short neighbour lists (flags
+// bit 1: scalar tails), goes to the instantiation without it; so does a workload on which most neighbours are new (pf_dense).
 bool probe_first(const cph_index* h) {
-    return h->bits == 4 && h->L.D == 128 && !(h->flags & 2u) && !h->pf_off && !h->pf_dense;
+    return h->L.D == 128 && !(h->flags & 2u) && !h->pf_off && !h->pf_dense;
 }
 
 void require_finalized(cph_index* h) {
@@ -376,10 +376,13 @@ BatchSet& next_set(cph_index* h, hipStream_t st) {
         // fetched); on a workload where most expansions find new neighbours in every group of eight it only adds a
         // dependent round trip (Gaussian 1M at 4 bits: 9.7 new per expansion, 13 % slower with it).  Decided from the
         // finished batches' own counters, with hysteresis; results are the same either way.
+        // Narrow codes have less to skip (512 B / 1 KB of codes against 2 KB) and lose the estimator's overlap with the
+        // probe: their break-even is lower (2-bit: +12 % at 1.5 new per expansion, -3.5 % at 5.3; 1-bit: +8 % at 1.0).
         if (o.pin_stats[0] >= 10000) {
             const double new_per_exp = (double)o.pin_stats[2] / (double)o.pin_stats[0];
-            if (new_per_exp > 6.0) h->pf_dense = true;
-            else if (new_per_exp < 4.5) h->pf_dense = false;
+            const double off = h->bits == 4 ? 6.0 : 2.8, on = h->bits == 4 ? 4.5 : 2.2;
+            if (new_per_exp > off) h->pf_dense = true;
+            else if (new_per_exp < on) h->pf_dense = false;
         }
     }
     if (s.used) HIP_CHECK(hipStreamWaitEvent(st, s.ev_done, 0));
@@ -516,11 +519,14 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     }
     const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
     if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
-    if ((mode != 0 || !probe_first(h)) && h->bits == 4 && h->L.D == 128) {
+    if ((mode != 0 || !probe_first(h)) && h->L.D == 128) {
         // a handful of queries: latency, not traffic -- the order of loads without the third dependent round trip.  Also
-        // the instantiation of the re-run launch (it takes the stage-2 decisions the probe-first one hands over) and of an
-        // index with short neighbour lists (flags bit 1): it evaluates their scalar tails.
-        hipLaunchKernelGGL((search_kernel<4, 128, false>), dim3(grid), dim3(64), lds, st, a);
+        // the instantiation of the re-run launch (it takes the stage-2 decisions the probe-first one hands over), of an
+        // index with short neighbour lists (flags bit 1: it evaluates their scalar tails) and of workloads on which
+        // probe first does not pay.
+        if (h->bits == 1) hipLaunchKernelGGL((search_kernel<1, 128, false>), dim3(grid), dim3(64), lds, st, a);
+        else if (h->bits == 2) hipLaunchKernelGGL((search_kernel<2, 128, false>), dim3(grid), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL((search_kernel<4, 128, false>), dim3(grid), dim3(64), lds, st, a);
         HIP_CHECK(hipGetLastError());
         return;
     }

@@ -857,22 +857,22 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
-            // PROBE FIRST (4-bit, D = 128; round 3).  The reference evaluates all 32 neighbours of a block, but only the NEW ones
+            // PROBE FIRST (D = 128; 4-bit codes in round 3, every width since round 4 -- the host picks the instantiation per
+            // workload).  The reference evaluates all 32 neighbours of a block, but only the NEW ones
             // -- 3.3 of 32 on the SIFT-like benchmark, none in a quarter of the expansions -- have any observable effect.  The
             // ids (128 B) decide that, so they, the norm and the vector go out here; the codes and aux values -- 2,560 of the
             // block's 2,752 bytes -- are fetched after the probe, by the lanes of the new neighbours only (both lane halves
             // of a neighbour; eight neighbours share a 128-byte line, so ~40 % of the lines drop out) and not at all when
             // nothing is new.  One more dependent round trip in three expansions out of four against ~40 % less traffic:
             // full queue 16.4 -> 15.3 ms per 100,000 queries, the 10,000-query launch 2.19 -> 2.14 ms, results identical.
-            // Narrow codes keep the block with the ids: their estimator runs under the probe's round trip.
+            // Whether it pays depends on how many neighbours are new: on the SIFT-like data (1-3 of 32) it gains 7-13 % at
+            // every bit width, on the Gaussian gate workloads (5-10 new, nothing to skip) it only adds a round trip (-3 % to
+            // -13 %): the library chooses from the previous batches' own counters (cphnsw_mi355x.hip: probe_first).  Without
+            // it the narrow codes run their estimator under the probe's round trip (kSpeculate).
 #ifdef CPH_NO_PROBE_FIRST
             constexpr bool kProbeFirst = false;
 #else
-#ifdef CPH_PROBE_FIRST_NARROW    // A/B switch: the narrow codes as well (they then lose the estimator's overlap with the probe)
             constexpr bool kProbeFirst = PF && SD == 128;
-#else
-            constexpr bool kProbeFirst = PF && BW == 4 && SD == 128;
-#endif
 #endif
             if constexpr (kProbeFirst) {
 #pragma unroll

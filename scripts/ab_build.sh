@@ -11,8 +11,7 @@ declare -A V=(
   [fine]="-DCPH_PHASE_TIMERS=2"                          # finer buckets along one expansion's dependent chain
   [traffic]="-DCPH_TRAFFIC_STATS"                        # what spilled beams and the estimated-set probe touch
   [launder]="-DCPH_LAUNDER_HOT"                          # hot heap routines recompute their lane arithmetic (fewer VGPRs)
-  [nopf]="-DCPH_NO_PROBE_FIRST"                          # 4-bit D=128: codes fetched with the ids (round-3 first half)
-  [pfnarrow]="-DCPH_PROBE_FIRST_NARROW"                  # probe first for 1- and 2-bit D=128 too
+  [nopf]="-DCPH_NO_PROBE_FIRST"                          # D=128: codes always fetched with the ids (the library never probes first)
   [noappend]="-DCPH_NO_SKIP_APPEND"                      # single push onto a spilled beam takes the append path
   [nolaundernn]="-DCPH_NO_LAUNDER_NN"                    # nn_push_wave keeps hoisted lane arithmetic
   [noloopwait]="-DCPH_NO_LOOPHEAD_WAIT"                  # no vmcnt(0) at the head of the expansion loop

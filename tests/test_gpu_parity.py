@@ -277,19 +277,22 @@ def test_large_index_against_oracle(cph, oracle, tmp_path):
             assert _beq(d, rd), (bits, k)
 
 
-@pytest.mark.parametrize("patch", [None, dict(search_gamma=1.15, gamma_max=1.6, gamma_beta=0.6, gamma_warmup=5)])
-def test_search_trajectory_counters_at_scale(cph, oracle, tmp_path, patch):
+@pytest.mark.parametrize("bits,patch", [(4, None), (4, dict(search_gamma=1.15, gamma_max=1.6, gamma_beta=0.6, gamma_warmup=5)),
+                                        (2, dict(search_gamma=1.15, gamma_max=1.6, gamma_beta=0.6, gamma_warmup=5)), (1, None)])
+def test_search_trajectory_counters_at_scale(cph, oracle, tmp_path, bits, patch):
     """Not only the top-k: the search PATH.  Per-query expansion counts and the batch totals of new neighbours, beam pushes
     and skipped stage-2 batches against the oracle's counters on a 60,000-vertex 4-bit index, 1,500 queries (~2 M
-    expansions) -- for the probe-first instantiation (the batch path of 4-bit D = 128, which sees only the NEW neighbours'
-    codes and has to reproduce the reference's stage-2 decision over ALL of a list, rabitq_search.hpp:178-187) and for the
-    instantiation without it (the small-batch launch).  With the builder's calibration (gamma ~ 1e9: DABS off) and with a
+    expansions; 20,000 vertices and 600 queries for the narrow codes, whose searches run longer) -- for the probe-first
+    instantiation (the first batch on a D = 128 index: it sees only the NEW neighbours' codes and has to reproduce the
+    reference's stage-2 decision over ALL of a list, rabitq_search.hpp:178-187) and for the instantiation without it (the
+    small-batch launch).  With the builder's calibration (gamma ~ 1e9: DABS off) and with a
     finite gamma patched in (DABS and gamma-termination on)."""
     from golden_util import apply_patch
     rng = np.random.default_rng(4242)
-    n, dim, bits, k = 60000, 128, 4, 10
-    X = rng.standard_normal((n, dim)).astype(np.float32)        # unclustered: ~1,000 expansions per query
-    Q = rng.standard_normal((1500, dim)).astype(np.float32)
+    n, dim, k = (60000 if bits == 4 else 20000), 128, 10
+    nq = 1500 if bits == 4 else 600
+    X = rng.standard_normal((n, dim)).astype(np.float32)        # unclustered: ~1,000 expansions per query at 4 bits
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
     ix = cph.CPIndex(dim, bits)
     ix.build(X)
     ix.finalize()
@@ -314,7 +317,7 @@ def test_search_trajectory_counters_at_scale(cph, oracle, tmp_path, patch):
     assert st["exact_l2"] >= int(ctr[:, 1].sum())                       # speculative reranks: a superset
     skipped = int(ctr[:, 6].sum())
     assert st["stage2_skipped"] <= skipped <= st["stage2_skipped"] + st["stage2_undecided"], (st, skipped)
-    print("trajectory:", {"patch": bool(patch), **st, "oracle_stage2_skipped": skipped})
+    print("trajectory:", {"bits": bits, "patch": bool(patch), **st, "oracle_stage2_skipped": skipped})
     # -- the small-batch launch: the instantiation without probe first decides every batch
     tot = dict(expansions=0, new_neighbours=0, beam_pushes=0, stage2_skipped=0, stage2_undecided=0, stage2_reruns=0)
     for lo in range(0, 320, 32):
