@@ -194,11 +194,11 @@ struct cph_index {
 
 namespace {
 
-// The batch launch of this index runs the probe-first instantiation of the search kernel (D = 128): it sees only the new
+// The batch launch of this index runs the probe-first instantiation of the search kernel (D = 128, D = 1024): it sees only the new
 // neighbours' codes, so a query whose stage-2 decision needs the others, and every index with short neighbour lists (flags
 // bit 1: scalar tails), goes to the instantiation without it; so does a workload on which most neighbours are new (pf_dense).
 bool probe_first(const cph_index* h) {
-    return h->L.D == 128 && !(h->flags & 2u) && !h->pf_off && !h->pf_dense;
+    return (h->L.D == 128 || h->L.D == 1024) && !(h->flags & 2u) && !h->pf_off && !h->pf_dense;
 }
 
 void require_finalized(cph_index* h) {
@@ -519,6 +519,13 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
     }
     const size_t lds = search_lds_bytes(h->L.D, h->L.PW, k);
     if (lds > 160 * 1024) throw InvalidArg("k too large for the on-chip result heap");
+    if ((mode != 0 || !probe_first(h)) && h->L.D == 1024) {
+        if (h->bits == 1) hipLaunchKernelGGL((search_kernel<1, 1024, false>), dim3(grid), dim3(64), lds, st, a);
+        else if (h->bits == 2) hipLaunchKernelGGL((search_kernel<2, 1024, false>), dim3(grid), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL((search_kernel<4, 1024, false>), dim3(grid), dim3(64), lds, st, a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if ((mode != 0 || !probe_first(h)) && h->L.D == 128) {
         // a handful of queries: latency, not traffic -- the order of loads without the third dependent round trip.  Also
         // the instantiation of the re-run launch (it takes the stage-2 decisions the probe-first one hands over), of an

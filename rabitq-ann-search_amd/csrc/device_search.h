@@ -857,8 +857,8 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
-            // PROBE FIRST (D = 128; 4-bit codes in round 3, every width since round 4 -- the host picks the instantiation per
-            // workload).  The reference evaluates all 32 neighbours of a block, but only the NEW ones
+            // PROBE FIRST (the static-D instantiations, D = 128 and D = 1024; 4-bit codes at D = 128 in round 3, every width and
+            // both shapes since round 4 -- the host picks the instantiation per workload).  The reference evaluates all 32 neighbours of a block, but only the NEW ones
             // -- 3.3 of 32 on the SIFT-like benchmark, none in a quarter of the expansions -- have any observable effect.  The
             // ids (128 B) decide that, so they, the norm and the vector go out here; the codes and aux values -- 2,560 of the
             // block's 2,752 bytes -- are fetched after the probe, by the lanes of the new neighbours only (both lane halves
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
 #ifdef CPH_NO_PROBE_FIRST
             constexpr bool kProbeFirst = false;
 #else
-            constexpr bool kProbeFirst = PF && SD == 128;
+            constexpr bool kProbeFirst = PF && SD >= 128;
 #endif
             if constexpr (kProbeFirst) {
 #pragma unroll
