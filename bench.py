@@ -449,7 +449,8 @@ def config_legs(args, t_start, failed):
                                    "--recall-queries", "200"], 900)
         cb = j.get("cpu_baseline", {})
         out["c3"] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
-                     "roofline": {k: j["roofline"][k] for k in ("kernel", "achieved", "frac", "kernel_ms", "pipelined_frac")},
+                     "roofline": {k: j["roofline"].get(k) for k in ("kernel", "achieved", "frac", "moved_frac", "traffic_over_algorithmic",
+                                                                    "kernel_ms", "pipelined_frac")},
                      "fastscan_stream_frac": j["fastscan_stream"]["roofline"]["frac"],
                      "index_build_s": j["config"]["index_build_s"], "reference_qps": cb.get("value"),
                      "parity_vs_reference": cb.get("parity_vs_reference"),
