@@ -440,7 +440,7 @@ def config_legs(args, t_start, failed):
     """The remaining BASELINE configs that fit one GPU in minutes, each as a condensed child line: C3 (GIST1M-class,
     D = 1024: build + timed steps + 1,000 queries against the compiled reference), C5 (streaming FastScan over the
     largest D = 1024 / 2-bit block set that fits, 64 blocks against the oracle) and -- if the run is younger than
-    --c4-deadline seconds when its turn comes (a 2.5-minute build) -- C4 (Deep10M-class, 10M x 96: 10k-query QPS, kernel
+    --c4-deadline seconds (230) when its turn comes (a 2.5-minute build; the legs before it take 185-205 s) -- C4 (Deep10M-class, 10M x 96: 10k-query QPS, kernel
     fraction, 500 queries against the compiled reference); else `legs_skipped` says so with the elapsed time.  A leg that
     breaks leaves an `error` object and its name in `failed`; the others still run."""
     out = {}
@@ -738,7 +738,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="c2 only: skip every child leg (gate workload, C3, C5)")
     ap.add_argument("--gate-config", default="recall1m", choices=["recall", "recall1m"])
     ap.add_argument("--gate4-k", type=int, default=500, help="k of the 4-bit gate leg (profiles/r4_gate_4bit_k_sweep.md)")
-    ap.add_argument("--c4-deadline", type=float, default=float(os.environ.get("CPH_BENCH_C4_DEADLINE", 200)),
+    ap.add_argument("--c4-deadline", type=float, default=float(os.environ.get("CPH_BENCH_C4_DEADLINE", 230)),
                     help="start the C4 leg (10M vectors: a 2.5-minute build) only if the run is younger than this many seconds; 0 = never")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("CPH_BENCH_CPU_THREADS", 16)),
                     help="OpenMP threads of the CPU baseline (default: the box' CPU share for one GPU)")
