@@ -29,8 +29,8 @@ The JSON line also carries
     on the SIFT-like data (our ids are the reference's bit for bit), so a short child run of the `recall1m` config --
     Gaussian data at the same scale, 1M x 128, 2-bit, k = 20, where it is -- is condensed into this object: QPS, recall,
     kernel fraction of HBM peak, the reference's QPS and the bit-level parity check on a bounded query sample,
-  * qps_at_recall_gate_4bit (c2, N = 1): the metric as worded -- the same data with 4-bit codes, k = 500 (the first k
-    of profiles/r4_gate_4bit_k_sweep.md that meets the gate),
+  * qps_at_recall_gate_4bit (c2, N = 1): the metric as worded -- the same data with 4-bit codes, k = 550 (the gate is met
+    from k = 500 on, profiles/r4_gate_4bit_k_sweep.md; 550 keeps a margin),
   * legs (c2, N = 1): condensed child lines of the BASELINE configs C3 (1M x 960), C5 (streaming FastScan over the
     largest block set that fits) and -- when the run is younger than --c4-deadline seconds at that point -- C4 (10M x
     96), each with its parity check; `legs_failed` lists legs that broke, `legs_skipped` the ones not started,
@@ -430,7 +430,8 @@ def recall_gate_leg(args):
 
 def recall_gate_leg_4bit(args):
     """The metric AS WORDED -- 4-bit codes: the same Gaussian 1M x 128 data at 4 bits reaches recall@10 >= 0.95 (first 10
-    unique ids of the k returned) from k = 500 on (profiles/r4_gate_4bit_k_sweep.md: 0.84 at k = 20, 0.93 at k = 200)."""
+    unique ids of the k returned) from k = 500 on (profiles/r4_gate_4bit_k_sweep.md: 0.84 at k = 20, 0.93 at k = 200); the
+    leg runs k = 550 (recall 0.958) so that the build-to-build spread of 0.001-0.002 cannot flip the verdict."""
     j, cmd = child_line(args, ["--config", args.gate_config, "--bits", "4", "--k", str(args.gate4_k), "--steps", "3", "--warmup", "1",
                                "--cpu-queries", "100", "--counter-queries", "50", "--recall-queries", "500"], 900)
     return _condense_gate(j, cmd)
@@ -737,7 +738,9 @@ def main():
     ap.add_argument("--no-recall-leg", action="store_true", help="c2 only: skip the short run of the gate workload")
     ap.add_argument("--no-extra-legs", action="store_true", help="c2 only: skip every child leg (gate workload, C3, C5)")
     ap.add_argument("--gate-config", default="recall1m", choices=["recall", "recall1m"])
-    ap.add_argument("--gate4-k", type=int, default=500, help="k of the 4-bit gate leg (profiles/r4_gate_4bit_k_sweep.md)")
+    ap.add_argument("--gate4-k", type=int, default=550,
+                    help="k of the 4-bit gate leg (profiles/r4_gate_4bit_k_sweep.md: the gate is met from k = 500 on, at 0.952-0.954 "
+                         "from build to build; 550 keeps half a percent of margin)")
     ap.add_argument("--c4-deadline", type=float, default=float(os.environ.get("CPH_BENCH_C4_DEADLINE", 230)),
                     help="start the C4 leg (10M vectors: a 2.5-minute build) only if the run is younger than this many seconds; 0 = never")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("CPH_BENCH_CPU_THREADS", 16)),
