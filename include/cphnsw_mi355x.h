@@ -28,8 +28,8 @@
  * device.  Threads: every entry point may be called from any thread.  Concurrent cph_search callers on one handle
  * are COALESCED into shared launches (the reference answers them in parallel under a shared lock,
  * src/bindings.cpp:146-175, api/hnsw_index.hpp:172): a caller that finds a free leader slot takes everybody queued
- * so far with the same k into one launch; each gets its own rows.  The other entry points serialise on the handle
- * (cph_search_batch_device only while it enqueues).  Knobs: CPH_LEADER_SLOTS (default 3), CPH_GATHER_US (150).
+ * so far with the same k into one launch; each waits for its own query only and gets its own rows.  The other entry points serialise on the handle
+ * (cph_search_batch_device only while it enqueues).  Knobs: CPH_LEADER_SLOTS (default 3), CPH_GATHER_US (80).
  * Returned ids are the reference's internal (post-BFS-reorder) node ids.
  */
 #ifndef CPHNSW_MI355X_H

@@ -184,9 +184,11 @@ struct cph_index {
     // a leader slot's resources: a stream, a pinned device-mapped I/O buffer and a batch set (sets[kMaxBatchSets + i])
     struct LeaderSlot {
         hipStream_t stream = nullptr;
-        uint8_t* pin = nullptr;
+        uint8_t* pin = nullptr;        // [flags kLeaderGroup x u32 | ids n*k*8 | dist n*k*4 | counts n*4 | queries n*dim*4]
         uint8_t* pin_dev = nullptr;
         size_t pin_bytes = 0;
+        uint32_t seq = 0;              // launch counter: the value the kernels write into the flags of THIS launch
+        uint64_t cur_n = 0, cur_k = 0; // shape of the launch in flight (for the callers' own copies)
     } leaders[kLeaderSlots];
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
@@ -471,9 +473,16 @@ void ensure_scratch(cph_index* h, BatchSet& s, uint32_t slots, uint64_t cap, hip
 
 // mode 0: the batch on the set's slots (capacity s.cap); 1: the overflow re-run on the full-capacity slots (its list of
 // queries lives on the device); 2: a batch small enough for the full-capacity slots, run there directly (no re-run needed)
+struct DoneFlags {          // per-query completion flags in pinned host memory (coalesced cph_search), or none
+    uint32_t* flags = nullptr;
+    uint32_t seq = 0;
+};
+
 void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist, uint32_t* d_count,
-                   const uint32_t* d_todo, int mode, hipStream_t st) {
+                   const uint32_t* d_todo, int mode, hipStream_t st, DoneFlags done = DoneFlags()) {
     SearchArgs a{};
+    a.done_flags = done.flags;
+    a.done_seq = done.seq;
     a.blocks = h->d_blocks.p;
     a.raw = h->d_raw.p;
     a.norm_sq = h->d_norm.p;
@@ -544,7 +553,7 @@ void launch_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* 
 // `st` and nothing waits for the device: a query that outgrows its scratch is answered by the
 // full-capacity re-run launch that always follows the main one (it finds an empty list otherwise).
 void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t* d_ids, float* d_dist,
-                    hipStream_t st, uint32_t* d_count_out = nullptr) {
+                    hipStream_t st, uint32_t* d_count_out = nullptr, DoneFlags done = DoneFlags()) {
     const uint64_t n = h->host.n;
     if (s.d_count.n < nq) {
         if (s.used) HIP_CHECK(hipEventSynchronize(s.ev_done));
@@ -615,10 +624,10 @@ void enqueue_search(cph_index* h, BatchSet& s, uint32_t nq, uint32_t k, int64_t*
         // a handful of queries: straight onto the full-capacity slots -- one launch, nothing can overflow
         s.run_slots = nq;
         s.run_cap = n + 1;
-        launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 2, st);
+        launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 2, st, done);
     } else {
-        launch_search(h, s, nq, k, d_ids, d_dist, d_count, d_order, 0, st);
-        if (rerun) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st);
+        launch_search(h, s, nq, k, d_ids, d_dist, d_count, d_order, 0, st, done);
+        if (rerun) launch_search(h, s, nq, k, d_ids, d_dist, d_count, nullptr, 1, st, done);
     }
     HIP_CHECK(hipEventRecord(s.ev1, st));
     // the statistics block lands in pinned host memory; it is only read when somebody asks.  (The private sets of the
@@ -667,7 +676,7 @@ SmallIo small_io(cph_index* h, BatchSet& s, uint64_t n, uint64_t k) {
 
 // diagnostic build (-DCPH_SEARCH_TRACE): where a coalesced cph_search launch spends its host time
 #ifdef CPH_SEARCH_TRACE
-static std::atomic<uint64_t> g_tr[6];   // groups, callers, ns waiting for the handle mutex, ns enqueuing, ns waiting for the device, ns copying out
+static std::atomic<uint64_t> g_tr[6];   // groups, callers, ns waiting for the handle mutex (per group), ns enqueuing (per group), ns each caller waited for its own query
 static inline uint64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define CPH_TR(i, v) g_tr[i] += (v)
 #else
@@ -734,8 +743,8 @@ int cph_destroy(cph_index* h) {
             if (s.pin_io) (void)hipHostFree(s.pin_io);
         }
 #ifdef CPH_SEARCH_TRACE
-        if (g_tr[0]) fprintf(stderr, "[search trace] groups=%llu callers=%llu per group: mutex wait %.1f us, enqueue %.1f us, device wait %.1f us, copy out %.1f us\n",
-                             (unsigned long long)g_tr[0], (unsigned long long)g_tr[1], g_tr[2] / 1e3 / g_tr[0], g_tr[3] / 1e3 / g_tr[0], g_tr[4] / 1e3 / g_tr[0], g_tr[5] / 1e3 / g_tr[0]);
+        if (g_tr[0]) fprintf(stderr, "[search trace] groups=%llu callers=%llu per group: mutex wait %.1f us, enqueue %.1f us; per caller: own-query wait %.1f us\n",
+                             (unsigned long long)g_tr[0], (unsigned long long)g_tr[1], g_tr[2] / 1e3 / g_tr[0], g_tr[3] / 1e3 / g_tr[0], g_tr[4] / 1e3 / g_tr[1]);
         for (auto& x : g_tr) x = 0;
 #endif
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1248,53 +1257,89 @@ int cph_search_batch_device(cph_index* h, const float* d_queries, uint64_t n, ui
     });
 }
 
-// One launch for up to kSmallBatch single-query callers with the same k: queries gathered into the leader slot's
-// pinned, device-mapped buffer, the copy-free small-batch path on the slot's own stream, every caller's own (unpadded)
-// result copied out.  The handle mutex is held while the launch is ENQUEUED, not while it runs: the next leader's
-// launch (other slot, other stream, the next batch set) overlaps this one.
-static void run_search_group(cph_index* h, cph_index::LeaderSlot& ls, const std::vector<SearchReq*>& group) {
+// One launch for up to kLeaderGroup single-query callers with the same k: queries gathered into the leader slot's
+// pinned, device-mapped buffer, the copy-free small-batch path on the slot's own stream.  The handle mutex is held while
+// the launch is ENQUEUED, not while it runs: the next leader's launch (other slot, other stream, its own batch set)
+// overlaps this one.  Nobody waits for the launch as a whole: the kernels raise a flag per query in the pinned buffer
+// once its results are visible to the host, and every caller waits for its own (wait_search_one).
+constexpr size_t kFlagBytes = kLeaderGroup * 4;
+struct GroupLayout {
+    size_t o_ids, o_dist, o_cnt, o_q, need;
+    GroupLayout(uint64_t n, uint64_t kk, uint64_t dim) {
+        o_ids = kFlagBytes;
+        o_dist = o_ids + n * kk * 8;
+        o_cnt = o_dist + n * kk * 4;
+        o_q = (o_cnt + n * 4 + 15) & ~(size_t)15;
+        need = o_q + n * dim * 4;
+    }
+};
+
+static void launch_search_group(cph_index* h, cph_index::LeaderSlot& ls, const std::vector<SearchReq*>& group) {
     const uint64_t n = group.size(), kk = group[0]->k;
     const uint64_t t0 = now_ns();
-    uint64_t t1 = 0, t2 = 0;
-    const size_t o_dist = n * kk * 8, o_cnt = o_dist + n * kk * 4, o_q = (o_cnt + n * 4 + 15) & ~(size_t)15;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        t1 = now_ns();
-        require_finalized(h);
-        h->use_device();
-        if (!ls.stream) HIP_CHECK(hipStreamCreateWithFlags(&ls.stream, hipStreamNonBlocking));
-        const size_t need = o_q + n * h->dim * 4;
-        if (ls.pin_bytes < need) {          // (the slot is ours alone: nothing in flight reads the old buffer)
-            if (ls.pin) HIP_CHECK(hipHostFree(ls.pin));
-            ls.pin = nullptr; ls.pin_bytes = 0;
-            const size_t bytes = std::max<size_t>(need * 2, 64 * 1024);
-            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ls.pin), bytes, hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ls.pin_dev), ls.pin, 0));
-            ls.pin_bytes = bytes;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const uint64_t t1 = now_ns();
+    require_finalized(h);
+    h->use_device();
+    if (!ls.stream) HIP_CHECK(hipStreamCreateWithFlags(&ls.stream, hipStreamNonBlocking));
+    const GroupLayout g(n, kk, h->dim);
+    if (ls.pin_bytes < g.need) {          // (the slot is ours alone: nothing in flight reads the old buffer)
+        if (ls.pin) HIP_CHECK(hipHostFree(ls.pin));
+        ls.pin = nullptr; ls.pin_bytes = 0;
+        const size_t bytes = std::max<size_t>(g.need * 2, 64 * 1024);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&ls.pin), bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&ls.pin_dev), ls.pin, 0));
+        std::memset(ls.pin, 0, kFlagBytes);
+        ls.pin_bytes = bytes;
+    }
+    float* h_query = reinterpret_cast<float*>(ls.pin + g.o_q);
+    for (uint64_t i = 0; i < n; ++i) std::memcpy(h_query + i * h->dim, group[i]->query, h->dim * sizeof(float));
+    if (++ls.seq == 0) ls.seq = 1;                                     // (a flag never holds a future launch's number)
+    ls.cur_n = n; ls.cur_k = kk;
+    BatchSet& s = h->sets[kMaxBatchSets + (&ls - h->leaders)];         // the slot's own set: its launches are ordered by its stream
+    init_set(s);
+    stage_queries(h, s, reinterpret_cast<const float*>(ls.pin_dev + g.o_q), n, ls.stream);      // the encoder reads the queries over PCIe
+    DoneFlags done;
+    done.flags = reinterpret_cast<uint32_t*>(ls.pin_dev);
+    done.seq = ls.seq;
+    enqueue_search(h, s, (uint32_t)n, (uint32_t)kk, reinterpret_cast<int64_t*>(ls.pin_dev + g.o_ids), reinterpret_cast<float*>(ls.pin_dev + g.o_dist),
+                   ls.stream, reinterpret_cast<uint32_t*>(ls.pin_dev + g.o_cnt), done);           // ... the search writes the results back
+    CPH_TR(0, 1); CPH_TR(1, n); CPH_TR(2, t1 - t0); CPH_TR(3, now_ns() - t1);
+}
+
+// Caller `index` of the launch in flight on this slot: wait for ITS query's flag, copy ITS rows out.  A launch lasts as
+// long as its longest query; a caller does not have to.  Polls the flag (pinned host memory, written by the kernel behind
+// a system-scope fence), looks at the stream every thousand polls so that a launch that died cannot hang its callers,
+// and gives the core away once it has spun for a while.
+static void wait_search_one(cph_index* h, cph_index::LeaderSlot& ls, uint32_t index, SearchReq& r) {
+    const uint64_t t0 = now_ns();
+    const uint32_t seq = ls.seq;
+    const uint64_t n = ls.cur_n, kk = ls.cur_k;
+    const uint32_t* flag = reinterpret_cast<const uint32_t*>(ls.pin) + index;
+    const auto spin_start = std::chrono::steady_clock::now();
+    bool dev_set = false;
+    for (uint64_t it = 1;; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((it & 1023) == 0) {
+            if (!dev_set) { HIP_CHECK(hipSetDevice(h->device)); dev_set = true; }
+            const hipError_t e = hipStreamQuery(ls.stream);
+            if (e == hipSuccess) {                 // the stream is idle: the flag is there now, or it never will be
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+                throw std::runtime_error("search launch finished without an answer for this query");
+            }
+            if (e != hipErrorNotReady) HIP_CHECK(e);
+            if (std::chrono::steady_clock::now() - spin_start > std::chrono::microseconds(300)) std::this_thread::yield();
+        } else {
+            __builtin_ia32_pause();
         }
-        float* h_query = reinterpret_cast<float*>(ls.pin + o_q);
-        for (uint64_t i = 0; i < n; ++i) std::memcpy(h_query + i * h->dim, group[i]->query, h->dim * sizeof(float));
-        BatchSet& s = h->sets[kMaxBatchSets + (&ls - h->leaders)];     // the slot's own set: its launches are ordered by its stream
-        init_set(s);
-        stage_queries(h, s, reinterpret_cast<const float*>(ls.pin_dev + o_q), n, ls.stream);      // the encoder reads the queries over PCIe
-        enqueue_search(h, s, (uint32_t)n, (uint32_t)kk, reinterpret_cast<int64_t*>(ls.pin_dev), reinterpret_cast<float*>(ls.pin_dev + o_dist),
-                       ls.stream, reinterpret_cast<uint32_t*>(ls.pin_dev + o_cnt));                 // ... the search writes the results back
-        t2 = now_ns();
     }
-    HIP_CHECK(hipSetDevice(h->device));
-    HIP_CHECK(hipStreamSynchronize(ls.stream));
-    const uint64_t t3 = now_ns();
-    const int64_t* h_ids = reinterpret_cast<const int64_t*>(ls.pin);
-    const float* h_dist = reinterpret_cast<const float*>(ls.pin + o_dist);
-    const uint32_t* h_count = reinterpret_cast<const uint32_t*>(ls.pin + o_cnt);
-    for (uint64_t i = 0; i < n; ++i) {
-        // the reference returns every result it found (<= max(k,1)); the caller's buffers hold max(k,1) entries
-        const uint32_t cnt = h_count[i];
-        std::memcpy(group[i]->ids, h_ids + i * kk, (size_t)cnt * 8);
-        std::memcpy(group[i]->dist, h_dist + i * kk, (size_t)cnt * 4);
-        *group[i]->m = cnt;
-    }
-    CPH_TR(0, 1); CPH_TR(1, n); CPH_TR(2, t1 - t0); CPH_TR(3, t2 - t1); CPH_TR(4, t3 - t2); CPH_TR(5, now_ns() - t3);
+    const GroupLayout g(n, kk, h->dim);
+    // the reference returns every result it found (<= max(k,1)); the caller's buffers hold max(k,1) entries
+    const uint32_t cnt = reinterpret_cast<const uint32_t*>(ls.pin + g.o_cnt)[index];
+    std::memcpy(r.ids, reinterpret_cast<const int64_t*>(ls.pin + g.o_ids) + (size_t)index * kk, (size_t)cnt * 8);
+    std::memcpy(r.dist, reinterpret_cast<const float*>(ls.pin + g.o_dist) + (size_t)index * kk, (size_t)cnt * 4);
+    *r.m = cnt;
+    CPH_TR(4, now_ns() - t0);
 }
 
 int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float* dist,
@@ -1307,7 +1352,9 @@ int cph_search(cph_index* h, const float* query, uint64_t k, int64_t* ids, float
         if (kk > 0xFFFFFFFFull) throw InvalidArg("k too large");
         r.query = query; r.k = kk; r.ids = ids; r.dist = dist; r.m = m;
         // concurrent callers are gathered into shared launches (search_coalescer.h); the status codes it records are cph_status
-        h->coal.submit(r, [&](int slot, const std::vector<SearchReq*>& group) { run_search_group(h, h->leaders[slot], group); });
+        h->coal.submit(r,
+                       [&](int slot, const std::vector<SearchReq*>& group) { launch_search_group(h, h->leaders[slot], group); },
+                       [&](int slot, uint32_t index, SearchReq& me) { wait_search_one(h, h->leaders[slot], index, me); });
     });
     if (rc != CPH_OK) return rc;
     return r.rc == CPH_OK ? CPH_OK : fail(r.rc, r.err);

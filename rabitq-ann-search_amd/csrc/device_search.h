@@ -72,6 +72,10 @@ struct SearchArgs {
     // re-run launch that follows on the same stream (no host round trip)
     uint32_t* redo;         // [nq] or null
     uint32_t* redo_count;
+    // optional (coalesced cph_search callers): done_flags[qi] = done_seq once query qi's results are visible to the HOST --
+    // the outputs then live in pinned, device-mapped memory and every caller waits for its own query only
+    uint32_t* done_flags;
+    uint32_t done_seq;
 };
 
 // Kernel arguments that are touched once per query (work queue, encoded-query arrays, outputs, statistics) are read from
@@ -1307,6 +1311,10 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 uint32_t* redo = CPH_COLD(redo);
                 if (redo) redo[atomicAdd(CPH_COLD(redo_count), 1u)] = qi;
             }
+        }
+        if (uint32_t* done_flags = CPH_COLD(done_flags); done_flags != nullptr && !overflow) {
+            __threadfence_system();      // every lane's result stores, and lane 0's count, before the flag
+            if (lane == 0) __hip_atomic_store(&done_flags[qi], CPH_COLD(done_seq), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // ---- clear the estimated set: un-mark the logged ids (or wipe after overflow) --
         __syncthreads();

@@ -2,12 +2,17 @@
 //
 // The reference answers concurrent search() calls in parallel under a shared lock (src/bindings.cpp:146-175,
 // api/hnsw_index.hpp:172).  A GPU answers them best TOGETHER: a caller that finds a free leader slot takes everybody who
-// queued up so far with the same k (at most `group_max`) into ONE launch; callers arriving while every slot is in flight
+// queued up so far with the same k (at most kLeaderGroup) into ONE launch; callers arriving while every slot is in flight
 // wait on a condition variable and are gathered by the next leader.  No spinning kernel, no extra thread; a lone caller
 // pays one uncontended mutex.  Callers that block on their answers come back together, so a leader whose slot's previous
 // launch answered several holds its launch for up to `gather_us` while the queue fills to that size (a lone caller never
-// waits).  The policy is separate from what a launch IS -- `Run(slot, group)` -- so that it can be exercised without a
-// GPU: tests/host_san runs it under ThreadSanitizer with a stand-in launch.
+// waits).
+//
+// A launch has two phases.  `launch(slot, group)` enqueues it (may throw: every member then fails with that error);
+// after it every member of the group -- the leader too -- calls `wait(slot, index, request)` for ITS OWN answer: a
+// launch lasts as long as its longest query, but a caller need not (the search kernel raises a flag per query in
+// pinned host memory).  The slot is free again when the last member has its answer.  The policy is separate from what
+// a launch IS so that it can be exercised without a GPU: tests/host_san runs it under ThreadSanitizer with a stand-in.
 #pragma once
 #include <algorithm>
 #include <chrono>
@@ -33,7 +38,11 @@ struct SearchReq {
     uint64_t* m = nullptr;
     int rc = 0;            // cph_status of the launch that answered (or failed) this caller
     std::string err;
-    bool done = false;
+    // set by the leader under the coalescer's mutex
+    bool launched = false; // the launch carrying this request is enqueued: wait() may be called
+    bool failed = false;   // ... or could not be: rc / err are set
+    int slot = -1;
+    uint32_t index = 0;    // position inside the launch
 };
 
 struct SearchCoalescer {
@@ -42,25 +51,27 @@ struct SearchCoalescer {
     std::deque<SearchReq*> waiting;
     struct Slot {
         bool busy = false;
+        size_t pending = 0;        // members of the launch in flight that have not got their answer yet
         size_t last_group = 0;     // callers its previous launch answered
     } slots[kLeaderSlots];
     int gathering = 0;             // leaders holding their launch back for callers that are about to come back
-    // Measured on the 1M x 128 benchmark index with 16 / 32 caller threads (profiles/r4_concurrent_search.md): 3 slots and
-    // a 150-us gathering window -- few, large launches: one launch answers 1 or 16 callers in nearly the same time (it
-    // lasts as long as its longest query), while more than three small launches in flight slow each other down.
+    // Measured on the 1M x 128 benchmark index with 16 / 32 caller threads (profiles/r4_concurrent_search.md): few, large
+    // launches -- one launch answers 1 or 16 callers in nearly the same time, while more than three small launches in
+    // flight slow each other down.
     int n_slots = 3;
-    int gather_us = 150;
+    int gather_us = 80;
     size_t group_bytes_max = 1u << 20;   // result entries (k x callers) one launch may carry
 
-    // Blocks until `r` has been answered by a launch (this caller's own or somebody else's).  run(slot, group) performs one
-    // launch for `group` (all with r.k == group[0]->k) and may throw; status codes: 1 = invalid argument, 2 = runtime
-    // error, 3 = out of memory (cph_status), written to every member of the group.
-    template <class Run>
-    void submit(SearchReq& r, Run&& run) {
+    // Blocks until `r` has its answer.  launch(slot, group): enqueue one launch for `group` (all with the same k); may
+    // throw -- status codes 1 = invalid argument, 2 = runtime error, 3 = out of memory (cph_status) then go to every
+    // member.  wait(slot, index, req): block until request `index` of the launch in `slot` is answered and copy it out;
+    // may throw (that member alone fails).
+    template <class Launch, class Wait>
+    void submit(SearchReq& r, Launch&& launch, Wait&& wait) {
         std::unique_lock<std::mutex> lk(mu);
         waiting.push_back(&r);
         if (gathering) cv.notify_all();
-        while (!r.done) {
+        while (!r.launched && !r.failed) {
             int slot = -1;
             for (int i = 0; i < n_slots; ++i) if (!slots[i].busy) { slot = i; break; }
             // (our request may already ride in another leader's launch: then there is nothing to lead)
@@ -75,7 +86,7 @@ struct SearchCoalescer {
                 ++gathering;
                 // (system_clock: libstdc++ turns a steady-clock wait into pthread_cond_clockwait, which GCC 11's
                 // ThreadSanitizer does not intercept -- it then reports a double lock that is not there; a clock step
-                // during a 150-us window at worst ends the window early or late once)
+                // during an 80-us window at worst ends the window early or late once)
                 cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(gather_us),
                               [&] { return waiting.size() >= want; });
                 --gathering;
@@ -97,13 +108,31 @@ struct SearchCoalescer {
             int rc = 0;
             std::string err;
             try {
-                run(slot, group);
+                launch(slot, group);
             } catch (const std::invalid_argument& e) { rc = 1; err = e.what();
             } catch (const std::bad_alloc&) { rc = 3; err = "out of memory";
             } catch (const std::exception& e) { rc = 2; err = e.what(); }
             lk.lock();
-            for (SearchReq* g : group) { g->rc = rc; g->err = err; g->done = true; }
             slots[slot].last_group = group.size();
+            if (rc != 0) {
+                for (SearchReq* g : group) { g->rc = rc; g->err = err; g->failed = true; }
+                slots[slot].busy = false;
+            } else {
+                slots[slot].pending = group.size();
+                for (uint32_t i = 0; i < group.size(); ++i) { group[i]->slot = slot; group[i]->index = i; group[i]->launched = true; }
+            }
+            cv.notify_all();
+        }
+        if (r.failed) return;
+        const int slot = r.slot;
+        lk.unlock();
+        try {
+            wait(slot, r.index, r);
+        } catch (const std::invalid_argument& e) { r.rc = 1; r.err = e.what();
+        } catch (const std::bad_alloc&) { r.rc = 3; r.err = "out of memory";
+        } catch (const std::exception& e) { r.rc = 2; r.err = e.what(); }
+        lk.lock();
+        if (--slots[slot].pending == 0) {      // the launch's pinned buffer is nobody's any more
             slots[slot].busy = false;
             cv.notify_all();
         }

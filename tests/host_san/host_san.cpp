@@ -333,34 +333,42 @@ static int run_threads_mode() {
 }
 
 // ---- the coalescing policy of concurrent cph_search callers (csrc/search_coalescer.h) with a stand-in launch -----
-// T threads x calls; the "launch" answers every member of its group from the member's own query value after a short
-// sleep (so that callers pile up), fails on purpose for k == 7, and records group sizes.  Every caller must be
-// answered exactly once, with ITS answer, errors must reach every member of the failing group, a group never mixes
-// k, never exceeds the cap, and no more launches than slots are in flight.
+// T threads x calls.  The stand-in "launch" gives every member of its group a completion time of its own (so that callers
+// pile up and members finish at different times, as queries of different length do) and fails on purpose for k == 7;
+// the stand-in "wait" sleeps until the member's time and answers from the member's own query value.  Every caller
+// must be answered exactly once, with ITS answer, errors must reach every member of the failing group, a group never
+// mixes k, never exceeds the cap, no more launches than slots are in flight, and a slot is not reused before the last
+// member of its launch has its answer.
 static int run_coalescer_mode() {
     using namespace cph;
     SearchCoalescer co;
     co.n_slots = 3;
     co.gather_us = 100;
-    std::atomic<int> in_flight{0}, max_in_flight{0}, launches{0}, max_group{0}, answered{0}, mixed{0};
-    auto run = [&](int slot, const std::vector<SearchReq*>& g) {
-        const int now = ++in_flight;
-        int prev = max_in_flight.load();
-        while (now > prev && !max_in_flight.compare_exchange_weak(prev, now)) {}
+    std::atomic<int> launches{0}, max_group{0}, answered{0}, mixed{0}, overlap{0};
+    std::atomic<int> slot_members[kLeaderSlots];
+    for (auto& x : slot_members) x = 0;
+    struct Flight { std::chrono::steady_clock::time_point ready[kLeaderGroup]; };
+    Flight flights[kLeaderSlots];
+    auto launch = [&](int slot, const std::vector<SearchReq*>& g) {
         ++launches;
         int pg = max_group.load();
         while ((int)g.size() > pg && !max_group.compare_exchange_weak(pg, (int)g.size())) {}
         REQUIRE(slot >= 0 && slot < co.n_slots);
         REQUIRE(!g.empty() && g.size() <= kLeaderGroup);
         for (SearchReq* r : g) if (r->k != g[0]->k) ++mixed;
-        std::this_thread::sleep_for(std::chrono::microseconds(200 + 30 * g.size()));
-        if (g[0]->k == 7) { --in_flight; throw std::runtime_error("stand-in launch failed"); }
-        for (SearchReq* r : g) {
-            r->ids[0] = (int64_t)(r->query[0] * 2.0f);      // "the answer" = a function of the caller's own query
-            r->dist[0] = r->query[0] + (float)r->k;
-            *r->m = 1;
-        }
-        --in_flight;
+        if (slot_members[slot].exchange((int)g.size()) != 0) ++overlap;      // the previous launch of this slot still had waiters
+        std::this_thread::sleep_for(std::chrono::microseconds(40));          // "enqueue"
+        if (g[0]->k == 7) { slot_members[slot] = 0; throw std::runtime_error("stand-in launch failed"); }
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < g.size(); ++i)
+            flights[slot].ready[i] = now + std::chrono::microseconds(150 + 37 * ((size_t)(g[i]->query[0]) % 7));
+    };
+    auto wait = [&](int slot, uint32_t index, SearchReq& r) {
+        std::this_thread::sleep_until(flights[slot].ready[index]);
+        r.ids[0] = (int64_t)(r.query[0] * 2.0f);      // "the answer" = a function of the caller's own query
+        r.dist[0] = r.query[0] + (float)r.k;
+        *r.m = 1;
+        --slot_members[slot];
     };
     const int T = 12, calls = 150;
     std::vector<std::thread> th;
@@ -373,7 +381,7 @@ static int run_coalescer_mode() {
             uint64_t m = 0;
             SearchReq r;
             r.query = &q; r.k = (uint64_t)((t % 4 == 3) ? 7 : (t % 3 == 0 ? 1 : 10)); r.ids = &id; r.dist = &d; r.m = &m;
-            co.submit(r, run);
+            co.submit(r, launch, wait);
             ++answered;
             if (r.k == 7) { if (r.rc != 2 || r.err != "stand-in launch failed") ++bad; }
             else if (r.rc != 0 || m != 1 || id != (int64_t)(q * 2.0f) || d != q + (float)r.k) ++bad;
@@ -383,11 +391,11 @@ static int run_coalescer_mode() {
     REQUIRE(answered.load() == T * calls);
     REQUIRE(bad.load() == 0);
     REQUIRE(mixed.load() == 0);
-    REQUIRE(max_in_flight.load() <= co.n_slots);
+    REQUIRE(overlap.load() == 0);
     REQUIRE(launches.load() < T * calls);          // callers WERE gathered
     REQUIRE(max_group.load() > 1);
     REQUIRE(co.waiting.empty() && co.gathering == 0);
-    for (int i = 0; i < co.n_slots; ++i) REQUIRE(!co.slots[i].busy);
+    for (int i = 0; i < co.n_slots; ++i) REQUIRE(!co.slots[i].busy && co.slots[i].pending == 0);
     // a lone caller is its own leader and never waits for the window
     {
         float q = 5.0f; int64_t id = 0; float d = 0; uint64_t m = 0;
@@ -395,12 +403,28 @@ static int run_coalescer_mode() {
         for (auto& sl : co.slots) sl.last_group = 1;
         const auto t0 = std::chrono::steady_clock::now();
         co.gather_us = 200000;
-        co.submit(r, run);
+        co.submit(r, launch, wait);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         REQUIRE(r.rc == 0 && id == 10 && ms < 100.0);
     }
-    std::printf("coalescer: ok (%d callers in %d launches, largest group %d, at most %d in flight)\n", T * calls, launches.load(),
-                max_group.load(), max_in_flight.load());
+    // an error in one member's wait is that member's alone
+    {
+        float q1 = 1.0f, q2 = 2.0f; int64_t id1 = 0, id2 = 0; float d1 = 0, d2 = 0; uint64_t m1 = 0, m2 = 0;
+        SearchReq a, b;
+        a.query = &q1; a.k = 10; a.ids = &id1; a.dist = &d1; a.m = &m1;
+        b.query = &q2; b.k = 10; b.ids = &id2; b.dist = &d2; b.m = &m2;
+        co.gather_us = 0;
+        auto wait2 = [&](int slot, uint32_t index, SearchReq& r) {
+            if (r.query[0] == 1.0f) { --slot_members[slot]; throw std::runtime_error("this member only"); }
+            wait(slot, index, r);
+        };
+        std::thread t1([&] { co.submit(a, launch, wait2); });
+        std::thread t2([&] { co.submit(b, launch, wait2); });
+        t1.join(); t2.join();
+        REQUIRE(a.rc == 2 && a.err == "this member only" && b.rc == 0 && id2 == 4);
+        for (int i = 0; i < co.n_slots; ++i) REQUIRE(!co.slots[i].busy && co.slots[i].pending == 0);
+    }
+    std::printf("coalescer: ok (%d callers in %d launches, largest group %d)\n", T * calls, launches.load(), max_group.load());
     return 0;
 }
 
