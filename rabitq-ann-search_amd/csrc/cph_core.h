@@ -43,6 +43,21 @@ struct DevLayout {
     uint32_t stride;   // block bytes (multiple of 64)
 };
 
+#ifndef CPH_BLOCK_ALIGN
+#define CPH_BLOCK_ALIGN 64u   // (128 -- a block never straddles one more 128-byte line than it needs -- measured: see DESIGN.md section 6)
+#endif
+// The byte offsets of make_dev_layout as compile-time constants, for the kernels with a compile-time D: a block's
+// address arithmetic then needs neither scalar registers for the layout nor (what the compiler did when it ran out of
+// them) a reload of it from the kernarg segment inside the expansion loop.
+template <int BW, int SD>
+struct StaticLayout {
+    static constexpr uint32_t kCodesBytes = 32u * (uint32_t)BW * (SD >= 32 ? (uint32_t)SD / 32u : 1u) * 4u;
+    static constexpr uint32_t kAuxOff = kCodesBytes;
+    static constexpr uint32_t kIdsOff = kAuxOff + 32u * 16u;
+    static constexpr uint32_t kCountOff = kIdsOff + 32u * 4u;
+    static constexpr uint32_t kStride = (kCountOff + 4u + CPH_BLOCK_ALIGN - 1u) / CPH_BLOCK_ALIGN * CPH_BLOCK_ALIGN;
+};
+
 inline DevLayout make_dev_layout(uint32_t D, uint32_t BW) {
     DevLayout L{};
     L.D = D;
@@ -61,9 +76,6 @@ inline DevLayout make_dev_layout(uint32_t D, uint32_t BW) {
     L.aux_off = L.codes_bytes;           // multiple of 128
     L.ids_off = L.aux_off + 32 * 16;
     L.count_off = L.ids_off + 32 * 4;
-#ifndef CPH_BLOCK_ALIGN
-#define CPH_BLOCK_ALIGN 64u   // (128 -- a block never straddles one more 128-byte line than it needs -- measured: see DESIGN.md section 6)
-#endif
     L.stride = (L.count_off + 4 + CPH_BLOCK_ALIGN - 1) / CPH_BLOCK_ALIGN * CPH_BLOCK_ALIGN;
     return L;
 }

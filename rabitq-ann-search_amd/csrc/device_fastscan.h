@@ -164,6 +164,15 @@ struct BlockLoads {
     uint4 c[kCPL];
     uint4 aux;
 
+    // aux offset known at compile time (see cph_core.h StaticLayout)
+    __device__ __forceinline__ void issue_static(const uint8_t* __restrict__ blk, int lane) {
+        static_assert(kStatic, "static D only");
+        const uint4* cp = reinterpret_cast<const uint4*>(blk) + (lane & (kNH * 32 - 1));
+#pragma unroll
+        for (int k = 0; k < kCPL; ++k) c[k] = cp[k * kNH * 32];
+        aux = reinterpret_cast<const uint4*>(blk + StaticLayout<BW, SD>::kAuxOff)[lane & 31];
+    }
+
     __device__ __forceinline__ void issue(const uint8_t* __restrict__ blk, const DevLayout& L, int lane) {
         if constexpr (kStatic) {
             const uint4* cp = reinterpret_cast<const uint4*>(blk) + (lane & (kNH * 32 - 1));

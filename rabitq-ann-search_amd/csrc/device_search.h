@@ -730,7 +730,14 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
 
         QP qp;
         qp.A = hd.A; qp.B = hd.B; qp.C = hd.C;
-        qp.affine_a = a.sc.affine_a; qp.affine_b = a.sc.affine_b; qp.floor = a.sc.ip_qo_floor;
+        {
+            // The estimator's calibration constants as opaque scalar values: left as plain kernarg reads the compiler
+            // re-reads them from the kernarg segment inside every expansion when it is short of scalar registers -- an
+            // s_load + s_waitcnt lgkmcnt(0) three times on the dependent chain (1 % of the kernel's time).
+            float af_a = a.sc.affine_a, af_b = a.sc.affine_b, fl = a.sc.ip_qo_floor;
+            asm volatile("" : "+s"(af_a), "+s"(af_b), "+s"(fl));
+            qp.affine_a = af_a; qp.affine_b = af_b; qp.floor = fl;
+        }
         qp.slack = s_slack[0];
         const float gamma = a.sc.gamma;
 
@@ -837,7 +844,13 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
 
             // ---- this expansion's loads, then the estimated-set probe (:227), a dependent round
             // trip that overlaps the exact distance and the result-heap push below ------------
-            const uint8_t* blk = a.blocks + (size_t)cur_id * a.L.stride;
+            // (compile-time layout for the probe-first instantiations -- cph_core.h StaticLayout: they re-read the layout from
+            // the kernarg segment inside the loop otherwise; the instantiations without it keep it in scalar registers, and
+            // lose their clean loop -- two scratch reloads in the pop -- when the constants change the allocation)
+            constexpr bool kStaticLayout = SD >= 128 && PF;
+            const uint32_t blk_stride = kStaticLayout ? StaticLayout<BW, SD>::kStride : a.L.stride;
+            const uint32_t blk_ids_off = kStaticLayout ? StaticLayout<BW, SD>::kIdsOff : a.L.ids_off;
+            const uint8_t* blk = a.blocks + (size_t)cur_id * blk_stride;
             const float* vrow = a.raw + (size_t)cur_id * D;
             // Nothing that matters is in flight here (the previous expansion's prefetch is thousands
             // of cycles old, its marking atomics return nothing).  Saying so with a wait the compiler
@@ -858,7 +871,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
                 __builtin_amdgcn_sched_barrier(0);
             }
             const float norm_ld = a.norm_sq[cur_id];
-            const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + a.L.ids_off)[li];
+            const uint32_t nid_ld = reinterpret_cast<const uint32_t*>(blk + blk_ids_off)[li];
             // ---- everything else this expansion reads is issued before the probe ----------
             BlockLoads<BW, SD> bl;
             // PROBE FIRST (the static-D instantiations, D = 128 and D = 1024; 4-bit codes at D = 128 in round 3, every width and
@@ -1097,7 +1110,7 @@ __global__ __launch_bounds__(64, search_waves_per_simd(SD, BW)) void search_kern
             }
             if constexpr (kProbeFirst) {
                 const bool fetch = ((new_mask >> (lane & 31)) & 1u) != 0u;       // both lane halves of a new neighbour
-                if (fetch) bl.issue(blk, a.L, lane);
+                if (fetch) bl.issue_static(blk, lane);
                 if (__builtin_expect(!estimate(fetch), 0)) { overflow = true; stage2_redo = true; break; }
             } else if constexpr (!kSpeculate) {
                 estimate(true);
