@@ -845,6 +845,10 @@ def main():
     tuning = None
     if args.streams > 0:
         n_streams = max(1, min(4, args.streams))
+    elif args.steps < 8:
+        # a handful of steps (the gate legs: 0.4-1.3 s per step) cannot fill four half-slot batches evenly -- three steps on four
+        # sets are two rounds of half a machine each (21 k instead of 26 k QPS on the 4-bit gate leg): two sets, every slot
+        n_streams = 2
     else:
         # Batches in flight: two sets with every slot, or four sets with half of the slots each (cph_set_batch_sets).
         # Which one packs the machine better depends on the length of the queries (C2: four, +5 %; C4: two, +9 %), so
