@@ -162,7 +162,7 @@ int cph_set_search_params(cph_index* h, uint32_t slots, uint64_t beam_capacity);
  * overflow, [6]=device time of the search launches in microseconds (HIP events on the launch
  * stream; with two batches in flight it includes the time shared with the other one),
  * [7]=expansions whose 32 neighbours were all estimated already, [8]=resident query slots used,
- * [9]=per-slot capacity that launch ran with, and for the probe-first instantiation (4-bit, D = 128), which fetches
+ * [9]=per-slot capacity that launch ran with, and for the probe-first instantiations (D = 128 and D = 1024 batch launches), which fetch
  * only the NEW neighbours' codes: [10]=queries (of [5]) handed to the re-run launch because the reference's stage-2
  * decision needed the rest of a block, [11]=expansions where that decision is unobservable and was left open -- there
  * [4] counts only the skips that were decided, a lower bound of the reference's counter (0 / exact for every other
