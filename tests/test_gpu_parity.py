@@ -694,3 +694,30 @@ def test_concurrent_search_calls_are_coalesced_and_exact(cph, gold, tmp_path):
     empty = cph.CPIndex(128, 4)
     with pytest.raises(RuntimeError):
         empty.search(np.zeros(128, np.float32), 10)
+
+
+@pytest.mark.parametrize("bits", [4, 1])
+def test_probe_first_at_d1024_matches_oracle(cph, oracle, tmp_path, bits):
+    """The D = 1024 instantiations with probe first (GIST1M-class shape; the committed D = 1024 fixture is 2-bit): a
+    4,000-vertex index of 960-dim clustered rows built here, the batch path (probe first + re-run launch) and the
+    small-batch launch (whole blocks) against the oracle -- ids, distance bits, per-query expansion counts, totals."""
+    rng = np.random.default_rng(960 + bits)
+    n, dim, k = 4000, 960, 10
+    cent = rng.random((40, dim)).astype(np.float32)
+    X = (cent[rng.integers(0, 40, n)] + 0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+    Q = (cent[rng.integers(0, 40, 200)] + 0.05 * rng.standard_normal((200, dim))).astype(np.float32)
+    ix = cph.CPIndex(dim, bits)
+    ix.build(X)
+    ix.finalize()
+    p = str(tmp_path / "d1024.idx")
+    ix.save(p)
+    oi = oracle.load(p)
+    oids, od, _, ctr = oi.search_batch(Q, k, nthreads=8, counters=True)
+    ids, d = ix.search_batch(Q, k)                        # 200 queries: the general path
+    st = ix.last_search_stats()
+    assert np.array_equal(ids, oids) and _beq(d, od)
+    assert np.array_equal(ix.last_query_expansions(len(Q)).astype(np.uint64), ctr[:, 0])
+    assert st["new_neighbours"] == int(ctr[:, 3].sum()) and st["beam_pushes"] == int(ctr[:, 4].sum()) - len(Q)
+    ids2, d2 = ix.search_batch(Q[:24], k)                 # the small-batch launch
+    assert np.array_equal(ids2, oids[:24]) and _beq(d2, od[:24])
+    assert np.array_equal(ix.last_query_expansions(24).astype(np.uint64), ctr[:24, 0])
